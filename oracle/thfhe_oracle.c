@@ -1,0 +1,895 @@
+/*
+ * thfhe_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See thfhe_oracle.h.
+ *
+ * Plain C restatement of the reference's gate-bootstrapping path with EXACT integer ring
+ * arithmetic.  Every function cites the reference lines it follows (paths relative to
+ * /root/reference, J/ = 3-gen-mk-tfhe/src/).  Two multiply engines give bit-identical results:
+ *   - schoolbook negacyclic convolution (the literal meaning of the reference's *_wo_FFT path)
+ *   - a 64-bit NTT over p = 2^64 - 2^32 + 1 with centred lifting (fast; used for batches and for
+ *     the cpu_baseline timing).  tests/test_oracle_units.py checks NTT == schoolbook.
+ * The GPU product uses a third, independent method (split-limb FP64 FFT), so GPU == oracle is a
+ * genuine cross-check.
+ */
+#include "thfhe_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+
+/* ============================================================================================
+ * Goldilocks field  p = 2^64 - 2^32 + 1
+ * ========================================================================================== */
+#define GL_P 0xFFFFFFFF00000001ULL
+#define GL_EPS 0xFFFFFFFFULL /* 2^64 mod p */
+
+static inline uint64_t gl_add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    if (s < a) s += GL_EPS; /* wrapped: +2^64 == +EPS (a,b < p so no second wrap) */
+    if (s >= GL_P) s -= GL_P;
+    return s;
+}
+static inline uint64_t gl_sub(uint64_t a, uint64_t b) { return (a >= b) ? a - b : a + (GL_P - b); }
+static inline uint64_t gl_reduce128(u128 x) {
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+    /* x = lo + hi_lo*2^64 + hi_hi*2^96 == lo + hi_lo*(2^32-1) - hi_hi  (mod p) */
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= GL_EPS;
+    uint64_t t1 = hi_lo * GL_EPS;
+    uint64_t r = t0 + t1;
+    if (r < t1) r += GL_EPS;
+    if (r >= GL_P) r -= GL_P;
+    return r;
+}
+static inline uint64_t gl_mul(uint64_t a, uint64_t b) { return gl_reduce128((u128)a * b); }
+static uint64_t gl_pow(uint64_t b, uint64_t e) {
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = gl_mul(r, b);
+        b = gl_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+static inline uint64_t gl_from_i64(int64_t v) { return v >= 0 ? (uint64_t)v : GL_P - (uint64_t)(-v); }
+static inline int64_t gl_to_centered(uint64_t r) { return (r > GL_P / 2) ? -(int64_t)(GL_P - r) : (int64_t)r; }
+
+typedef struct {
+    int N;
+    uint64_t *psi_rev;     /* psi^{bitrev(i)}  */
+    uint64_t *psi_inv_rev; /* psi^{-bitrev(i)} */
+    uint64_t n_inv;
+} gl_tables;
+
+#define GL_MAX_LOG 13
+static gl_tables g_tables[GL_MAX_LOG + 1];
+
+static unsigned bitrev(unsigned x, int bits) {
+    unsigned r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+static const gl_tables *gl_get_tables(int N) {
+    int lg = 0;
+    while ((1 << lg) < N) lg++;
+    if (lg > GL_MAX_LOG || (1 << lg) != N) abort();
+    gl_tables *t = &g_tables[lg];
+    if (t->N == N) return t;
+#pragma omp critical(gl_tables_init)
+    {
+        if (t->N != N) {
+            uint64_t psi = gl_pow(7, (GL_P - 1) / (2 * (uint64_t)N)); /* 7 generates F_p^* */
+            uint64_t psi_inv = gl_pow(psi, GL_P - 2);
+            uint64_t *pr = (uint64_t *)malloc(sizeof(uint64_t) * N);
+            uint64_t *pir = (uint64_t *)malloc(sizeof(uint64_t) * N);
+            uint64_t a = 1, b = 1;
+            for (int i = 0; i < N; i++) {
+                unsigned j = bitrev((unsigned)i, lg);
+                pr[j] = a;
+                pir[j] = b;
+                a = gl_mul(a, psi);
+                b = gl_mul(b, psi_inv);
+            }
+            t->psi_rev = pr;
+            t->psi_inv_rev = pir;
+            t->n_inv = gl_pow((uint64_t)N, GL_P - 2);
+#pragma omp flush
+            t->N = N;
+        }
+    }
+    return t;
+}
+
+/* negacyclic forward NTT, natural order in -> bit-reversed out (Cooley-Tukey, merged psi twist) */
+static void gl_ntt_fwd(uint64_t *a, const gl_tables *T) {
+    int N = T->N, t = N;
+    for (int m = 1; m < N; m <<= 1) {
+        t >>= 1;
+        for (int i = 0; i < m; i++) {
+            int j1 = 2 * i * t;
+            uint64_t S = T->psi_rev[m + i];
+            for (int j = j1; j < j1 + t; j++) {
+                uint64_t U = a[j], V = gl_mul(a[j + t], S);
+                a[j] = gl_add(U, V);
+                a[j + t] = gl_sub(U, V);
+            }
+        }
+    }
+}
+/* inverse: bit-reversed in -> natural out (Gentleman-Sande), includes 1/N */
+static void gl_ntt_inv(uint64_t *a, const gl_tables *T) {
+    int N = T->N, t = 1;
+    for (int m = N; m > 1; m >>= 1) {
+        int j1 = 0, h = m >> 1;
+        for (int i = 0; i < h; i++) {
+            uint64_t S = T->psi_inv_rev[h + i];
+            for (int j = j1; j < j1 + t; j++) {
+                uint64_t U = a[j], V = a[j + t];
+                a[j] = gl_add(U, V);
+                a[j + t] = gl_mul(gl_sub(U, V), S);
+            }
+            j1 += 2 * t;
+        }
+        t <<= 1;
+    }
+    for (int j = 0; j < N; j++) a[j] = gl_mul(a[j], T->n_inv);
+}
+
+/* ============================================================================================
+ * scalar helpers
+ * ========================================================================================== */
+static int ilog2(int x) {
+    int l = 0;
+    while ((1 << l) < x) l++;
+    return l;
+}
+
+/* decode_message(phase, 2N): (x + 2^(32-log2(2N)-1)) >> (32-log2(2N)), arithmetic
+ * J/numeric-functions.jl:70-73 ; result in [-N, N) */
+int32_t oracle_modswitch(int32_t x, int32_t N) {
+    int lg = ilog2(2 * N);
+    int32_t y = (int32_t)((uint32_t)x + (1u << (32 - lg - 1)));
+    return y >> (32 - lg); /* arithmetic shift of a negative int32: gcc/clang implement it as such */
+}
+
+/* X^shift * p mod X^N+1, any integer shift (taken mod 2N)    J/rlwe.jl:130-131 (DarkIntegers mul_by_monomial) */
+void oracle_mul_by_monomial32(const int32_t *p, int32_t shift, int32_t N, int32_t *out) {
+    int32_t s = ((shift % (2 * N)) + 2 * N) % (2 * N);
+    for (int j = 0; j < N; j++) {
+        int d = j + s; /* destination exponent in [0, 3N) */
+        int neg = 0;
+        while (d >= N) {
+            d -= N;
+            neg ^= 1;
+        }
+        out[d] = neg ? (int32_t)(0u - (uint32_t)p[j]) : p[j];
+    }
+}
+void oracle_mul_by_monomial64(const int64_t *p, int32_t shift, int32_t N, int64_t *out) {
+    int32_t s = ((shift % (2 * N)) + 2 * N) % (2 * N);
+    for (int j = 0; j < N; j++) {
+        int d = j + s;
+        int neg = 0;
+        while (d >= N) {
+            d -= N;
+            neg ^= 1;
+        }
+        out[d] = neg ? (int64_t)(0ull - (uint64_t)p[j]) : p[j];
+    }
+}
+
+/* signed gadget decomposition    J/tgsw.jl:112-138, offset from J/tgsw.jl:26-30 */
+void oracle_decompose32(const int32_t *p, int32_t N, int32_t l, int32_t Bgbit, int32_t *digits) {
+    uint32_t mask = (1u << Bgbit) - 1u, half = 1u << (Bgbit - 1), offset = 0;
+    for (int q = 1; q <= l; q++) offset += half << (32 - q * Bgbit);
+    for (int q = 1; q <= l; q++)
+        for (int j = 0; j < N; j++) {
+            uint32_t v = (uint32_t)p[j] + offset;
+            digits[(q - 1) * N + j] = (int32_t)((v >> (32 - q * Bgbit)) & mask) - (int32_t)half;
+        }
+}
+void oracle_decompose64(const int64_t *p, int32_t N, int32_t l, int32_t Bgbit, int64_t *digits) {
+    uint64_t mask = (1ull << Bgbit) - 1ull, half = 1ull << (Bgbit - 1), offset = 0;
+    for (int q = 1; q <= l; q++) offset += half << (64 - q * Bgbit);
+    for (int q = 1; q <= l; q++)
+        for (int j = 0; j < N; j++) {
+            uint64_t v = (uint64_t)p[j] + offset;
+            digits[(size_t)(q - 1) * N + j] = (int64_t)((v >> (64 - q * Bgbit)) & mask) - (int64_t)half;
+        }
+}
+
+/* exact negacyclic products (the reference's IntPolynomial * TorusPolynomial of the _wo_FFT path) */
+void oracle_polymul_schoolbook32(const int32_t *a, const int32_t *b, int32_t N, int32_t *out) {
+    uint32_t *acc = (uint32_t *)calloc((size_t)N, sizeof(uint32_t));
+    for (int i = 0; i < N; i++) {
+        uint32_t ai = (uint32_t)a[i];
+        if (!ai) continue;
+        for (int j = 0; j < N - i; j++) acc[i + j] += ai * (uint32_t)b[j];
+        for (int j = N - i; j < N; j++) acc[i + j - N] -= ai * (uint32_t)b[j];
+    }
+    memcpy(out, acc, sizeof(uint32_t) * (size_t)N);
+    free(acc);
+}
+void oracle_polymul_schoolbook64(const int64_t *a, const int64_t *b, int32_t N, int64_t *out) {
+    uint64_t *acc = (uint64_t *)calloc((size_t)N, sizeof(uint64_t));
+    for (int i = 0; i < N; i++) {
+        uint64_t ai = (uint64_t)a[i];
+        if (!ai) continue;
+        for (int j = 0; j < N - i; j++) acc[i + j] += ai * (uint64_t)b[j];
+        for (int j = N - i; j < N; j++) acc[i + j - N] -= ai * (uint64_t)b[j];
+    }
+    memcpy(out, acc, sizeof(uint64_t) * (size_t)N);
+    free(acc);
+}
+
+/* exact product via NTT: requires sum |small_i * b_j| < p/2, i.e. |small| < 2^15 with int32 b and N <= 2^13 */
+void oracle_polymul_ntt32(const int32_t *small, const int32_t *b, int32_t N, int32_t *out) {
+    const gl_tables *T = gl_get_tables(N);
+    uint64_t *x = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)N), *y = x + N;
+    for (int j = 0; j < N; j++) {
+        x[j] = gl_from_i64(small[j]);
+        y[j] = gl_from_i64(b[j]);
+    }
+    gl_ntt_fwd(x, T);
+    gl_ntt_fwd(y, T);
+    for (int j = 0; j < N; j++) x[j] = gl_mul(x[j], y[j]);
+    gl_ntt_inv(x, T);
+    for (int j = 0; j < N; j++) out[j] = (int32_t)(uint32_t)(uint64_t)gl_to_centered(x[j]);
+    free(x);
+}
+/* Torus64: b = b_hi*2^32 + b_lo (b_lo unsigned 32, b_hi signed 32); both partial products exact */
+void oracle_polymul_ntt64(const int64_t *small, const int64_t *b, int32_t N, int64_t *out) {
+    const gl_tables *T = gl_get_tables(N);
+    uint64_t *x = (uint64_t *)malloc(sizeof(uint64_t) * 3 * (size_t)N), *lo = x + N, *hi = x + 2 * N;
+    for (int j = 0; j < N; j++) {
+        x[j] = gl_from_i64(small[j]);
+        lo[j] = (uint64_t)b[j] & 0xFFFFFFFFull;
+        hi[j] = gl_from_i64(b[j] >> 32);
+    }
+    gl_ntt_fwd(x, T);
+    gl_ntt_fwd(lo, T);
+    gl_ntt_fwd(hi, T);
+    for (int j = 0; j < N; j++) {
+        lo[j] = gl_mul(x[j], lo[j]);
+        hi[j] = gl_mul(x[j], hi[j]);
+    }
+    gl_ntt_inv(lo, T);
+    gl_ntt_inv(hi, T);
+    for (int j = 0; j < N; j++)
+        out[j] = (int64_t)((uint64_t)gl_to_centered(lo[j]) + ((uint64_t)gl_to_centered(hi[j]) << 32));
+    free(x);
+}
+
+/* t64tot32(d) = trunc(Int32, d / 2^32): Int64 -> Float64 (round-to-nearest-even), exact divide,
+ * truncate toward zero.  J/numeric-functions.jl:109-111.  (Julia would throw InexactError when
+ * the double reaches 2^31, i.e. d >= 2^63-512; we wrap that measure-zero case to INT32_MIN.) */
+int32_t oracle_t64tot32(int64_t d) {
+    double v = (double)d / 4294967296.0;
+    v = trunc(v);
+    if (v >= 2147483648.0) return INT32_MIN;
+    return (int32_t)v;
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ============================================================================================
+ * single-key context
+ * ========================================================================================== */
+struct oracle_ctx {
+    oracle_params p;
+    const int32_t *bk;  /* borrowed */
+    const int32_t *ksk; /* borrowed */
+    uint64_t *bk_ntt;   /* [n][(k+1)l][k+1][N] NTT domain */
+};
+
+oracle_ctx *oracle_ctx_create(const oracle_params *p, const int32_t *bk, const int32_t *ksk) {
+    if (p->torus_bits != 32 || p->parties != 1) return NULL;
+    oracle_ctx *c = (oracle_ctx *)calloc(1, sizeof(*c));
+    c->p = *p;
+    c->bk = bk;
+    c->ksk = ksk;
+    const int N = p->N;
+    const gl_tables *T = gl_get_tables(N);
+    size_t polys = (size_t)p->n * (p->k + 1) * p->l * (p->k + 1);
+    c->bk_ntt = (uint64_t *)malloc(polys * N * sizeof(uint64_t));
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)polys; q++) {
+        uint64_t *dst = c->bk_ntt + (size_t)q * N;
+        const int32_t *src = bk + (size_t)q * N;
+        for (int j = 0; j < N; j++) dst[j] = gl_from_i64(src[j]);
+        gl_ntt_fwd(dst, T);
+    }
+    return c;
+}
+void oracle_ctx_destroy(oracle_ctx *c) {
+    if (!c) return;
+    free(c->bk_ntt);
+    free(c);
+}
+
+/* tgsw_extern_mul: out[c] = sum_{j,p} digit_p(tmp[j]) (*) BK_i[j*l+p][c]     J/tgsw.jl:146-156 */
+static void extern_mul32(const oracle_ctx *c, int32_t i, const int32_t *tmp, int32_t *out, int use_schoolbook) {
+    const int N = c->p.N, k = c->p.k, l = c->p.l, rows = (k + 1) * l;
+    int32_t *dig = (int32_t *)malloc(sizeof(int32_t) * (size_t)rows * N);
+    for (int j = 0; j <= k; j++) oracle_decompose32(tmp + (size_t)j * N, N, l, c->p.Bgbit, dig + (size_t)j * l * N);
+    if (use_schoolbook) {
+        int32_t *prod = (int32_t *)malloc(sizeof(int32_t) * N);
+        memset(out, 0, sizeof(int32_t) * (size_t)(k + 1) * N);
+        for (int r = 0; r < rows; r++)
+            for (int cc = 0; cc <= k; cc++) {
+                const int32_t *row = c->bk + (((size_t)i * rows + r) * (k + 1) + cc) * N;
+                oracle_polymul_schoolbook32(dig + (size_t)r * N, row, N, prod);
+                for (int j = 0; j < N; j++)
+                    out[(size_t)cc * N + j] = (int32_t)((uint32_t)out[(size_t)cc * N + j] + (uint32_t)prod[j]);
+            }
+        free(prod);
+    } else {
+        const gl_tables *T = gl_get_tables(N);
+        uint64_t *d = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(rows + k + 1) * N), *acc = d + (size_t)rows * N;
+        for (int r = 0; r < rows; r++) {
+            for (int j = 0; j < N; j++) d[(size_t)r * N + j] = gl_from_i64(dig[(size_t)r * N + j]);
+            gl_ntt_fwd(d + (size_t)r * N, T);
+        }
+        for (int cc = 0; cc <= k; cc++) {
+            uint64_t *a = acc + (size_t)cc * N;
+            for (int j = 0; j < N; j++) {
+                /* lazy accumulation of up to 8 products in 128 bits would overflow; reduce each */
+                uint64_t s = 0;
+                for (int r = 0; r < rows; r++)
+                    s = gl_add(s, gl_mul(d[(size_t)r * N + j], c->bk_ntt[(((size_t)i * rows + r) * (k + 1) + cc) * N + j]));
+                a[j] = s;
+            }
+            gl_ntt_inv(a, T);
+            for (int j = 0; j < N; j++) out[(size_t)cc * N + j] = (int32_t)(uint32_t)(uint64_t)gl_to_centered(a[j]);
+        }
+        free(d);
+    }
+    free(dig);
+}
+
+/* mux_rotate: acc += BK_i (.) (X^barai * acc - acc)        J/bootstrap.jl:19-23 */
+void oracle_mux_rotate(const oracle_ctx *c, int32_t i, int32_t barai, int32_t *acc, int use_schoolbook) {
+    const int N = c->p.N, k = c->p.k;
+    size_t sz = (size_t)(k + 1) * N;
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * 2 * sz), *ext = tmp + sz;
+    for (int j = 0; j <= k; j++) {
+        oracle_mul_by_monomial32(acc + (size_t)j * N, barai, N, tmp + (size_t)j * N);
+        for (int q = 0; q < N; q++)
+            tmp[(size_t)j * N + q] = (int32_t)((uint32_t)tmp[(size_t)j * N + q] - (uint32_t)acc[(size_t)j * N + q]);
+    }
+    extern_mul32(c, i, tmp, ext, use_schoolbook);
+    for (size_t q = 0; q < sz; q++) acc[q] = (int32_t)((uint32_t)acc[q] + (uint32_t)ext[q]);
+    free(tmp);
+}
+
+/* rlwe_extract_sample: a'_0 = a_0, a'_j = -a_{N-j}, b' = body_0     J/rlwe.jl:64-68, J/polynomials.jl:69-72 */
+static void extract32(const int32_t *acc, int N, int k, int32_t *out) {
+    for (int m = 0; m < k; m++) {
+        const int32_t *a = acc + (size_t)m * N;
+        out[(size_t)m * N] = a[0];
+        for (int j = 1; j < N; j++) out[(size_t)m * N + j] = (int32_t)(0u - (uint32_t)a[N - j]);
+    }
+    out[(size_t)k * N] = acc[(size_t)k * N];
+}
+
+/* bootstrap_wo_keyswitch + blind_rotate_and_extract + blind_rotate     J/bootstrap.jl:38-88 */
+void oracle_bootstrap_wo_keyswitch(const oracle_ctx *c, int32_t mu, const int32_t *x, int32_t *out, int use_schoolbook) {
+    const int N = c->p.N, k = c->p.k, n = c->p.n;
+    int32_t barb = oracle_modswitch(x[n], N);
+    size_t sz = (size_t)(k + 1) * N;
+    int32_t *acc = (int32_t *)calloc(sz, sizeof(int32_t));
+    int32_t *tv = (int32_t *)malloc(sizeof(int32_t) * N);
+    for (int j = 0; j < N; j++) tv[j] = mu;
+    oracle_mul_by_monomial32(tv, -barb, N, acc + (size_t)k * N); /* acc = (0, X^{-barb} * testvect) */
+    for (int i = 0; i < n; i++) {
+        int32_t bara = oracle_modswitch(x[i], N);
+        if (bara != 0) oracle_mux_rotate(c, i, bara, acc, use_schoolbook);
+    }
+    extract32(acc, N, k, out);
+    free(tv);
+    free(acc);
+}
+
+/* keyswitch      J/keyswitch.jl:45-80 */
+static void keyswitch_with(const int32_t *ksk, int Nin, int n, int t, int basebit, const int32_t *in, int32_t b_init, int32_t *out) {
+    const int base = 1 << basebit;
+    const uint32_t mask = (uint32_t)base - 1u;
+    const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+    uint32_t *res = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
+    res[n] = (uint32_t)b_init;
+    for (int i = 0; i < Nin; i++) {
+        uint32_t aibar = (uint32_t)in[i] + prec_offset;
+        for (int j = 1; j <= t; j++) {
+            uint32_t d = (aibar >> (32 - j * basebit)) & mask;
+            if (d != 0) {
+                const int32_t *row = ksk + ((((size_t)i * t + (j - 1)) * (base - 1)) + (d - 1)) * ((size_t)n + 1);
+                for (int q = 0; q <= n; q++) res[q] -= (uint32_t)row[q];
+            }
+        }
+    }
+    memcpy(out, res, sizeof(uint32_t) * ((size_t)n + 1));
+    free(res);
+}
+void oracle_keyswitch(const oracle_ctx *c, const int32_t *in, int32_t *out) {
+    const int Nin = c->p.N * c->p.k;
+    keyswitch_with(c->ksk, Nin, c->p.n, c->p.ks_t, c->p.ks_basebit, in, in[Nin], out);
+}
+
+/* gate linear prologues: temp = (0, cb) + cx*x + cy*y      J/gates.jl:15-161 ; MUX J/gates.jl:163-177 */
+typedef struct {
+    int32_t cb, cx, cy;
+} lin_t;
+static int gate_lin(int op, int which, lin_t *L) {
+    const int32_t E8 = 1 << 29, E4 = 1 << 30; /* encode_message(1,8), encode_message(1,4)   J/numeric-functions.jl:86-89 */
+    switch (op) {
+    case OR_GATE_NAND: *L = (lin_t){E8, -1, -1}; return 0;
+    case OR_GATE_OR: *L = (lin_t){E8, 1, 1}; return 0;
+    case OR_GATE_AND: *L = (lin_t){-E8, 1, 1}; return 0;
+    case OR_GATE_XOR: *L = (lin_t){E4, 2, 2}; return 0;
+    case OR_GATE_XNOR: *L = (lin_t){-E4, -2, -2}; return 0;
+    case OR_GATE_NOR: *L = (lin_t){-E8, -1, -1}; return 0;
+    case OR_GATE_ANDNY: *L = (lin_t){-E8, -1, 1}; return 0;
+    case OR_GATE_ANDYN: *L = (lin_t){-E8, 1, -1}; return 0;
+    case OR_GATE_ORNY: *L = (lin_t){E8, -1, 1}; return 0;
+    case OR_GATE_ORYN: *L = (lin_t){E8, 1, -1}; return 0;
+    case OR_GATE_MUX: *L = which == 0 ? (lin_t){-E8, 1, 1} /* AND(x,y) */ : (lin_t){-E8, -1, 1} /* AND(NOT x, z) */; return 0;
+    default: return -1;
+    }
+}
+int oracle_gate_prologue(const oracle_params *p, int op, int which, const int32_t *in0, const int32_t *in1,
+                         const int32_t *in2, int32_t *tmp) {
+    lin_t L;
+    if (gate_lin(op, which, &L)) return -1;
+    const int32_t *y = (op == OR_GATE_MUX && which == 1) ? in2 : in1;
+    int words = p->n * p->parties;
+    for (int q = 0; q <= words; q++) {
+        uint32_t v = (uint32_t)L.cx * (uint32_t)in0[q] + (uint32_t)L.cy * (uint32_t)y[q];
+        if (q == words) v += (uint32_t)L.cb;
+        tmp[q] = (int32_t)v;
+    }
+    return 0;
+}
+
+int oracle_gates(const oracle_ctx *c, int op, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                 int32_t *out, size_t count, int use_schoolbook) {
+    const int n = c->p.n, Nk = c->p.N * c->p.k;
+    const size_t rec = (size_t)n + 1;
+    const int32_t MU = 1 << 29;
+    if (op == OR_GATE_NOT || op == OR_GATE_COPY) { /* J/gates.jl:76-79: not bootstrapped */
+        for (size_t g = 0; g < count * rec; g++) out[g] = op == OR_GATE_NOT ? (int32_t)(0u - (uint32_t)in0[g]) : in0[g];
+        return 0;
+    }
+    lin_t L;
+    if (gate_lin(op, 0, &L)) return -1;
+    int32_t *res = (int32_t *)malloc(sizeof(int32_t) * count * rec); /* tolerate out aliasing an input */
+#pragma omp parallel for schedule(dynamic)
+    for (long g = 0; g < (long)count; g++) {
+        int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (rec + 2 * ((size_t)Nk + 1)));
+        int32_t *u1 = tmp + rec, *u2 = u1 + Nk + 1;
+        const int32_t *x = in0 + g * rec, *y = in1 + g * rec, *z = in2 ? in2 + g * rec : NULL;
+        if (op != OR_GATE_MUX) {
+            oracle_gate_prologue(&c->p, op, 0, x, y, z, tmp);
+            oracle_bootstrap_wo_keyswitch(c, MU, tmp, u1, use_schoolbook);
+            oracle_keyswitch(c, u1, res + g * rec); /* bootstrap = wo_keyswitch + keyswitch, J/bootstrap.jl:98-101 */
+        } else {
+            oracle_gate_prologue(&c->p, op, 0, x, y, z, tmp);
+            oracle_bootstrap_wo_keyswitch(c, MU, tmp, u1, use_schoolbook);
+            oracle_gate_prologue(&c->p, op, 1, x, y, z, tmp);
+            oracle_bootstrap_wo_keyswitch(c, MU, tmp, u2, use_schoolbook);
+            for (int q = 0; q <= Nk; q++) u1[q] = (int32_t)((uint32_t)u1[q] + (uint32_t)u2[q]); /* t3 = (0,1/8)+u1+u2 */
+            u1[Nk] = (int32_t)((uint32_t)u1[Nk] + (uint32_t)MU);
+            oracle_keyswitch(c, u1, res + g * rec);
+        }
+        free(tmp);
+    }
+    memcpy(out, res, sizeof(int32_t) * count * rec);
+    free(res);
+    return 0;
+}
+
+/* ============================================================================================
+ * 3-gen multi-key context
+ * ========================================================================================== */
+struct oracle_mk_ctx {
+    oracle_params p;
+    const int64_t *bk;
+    const int32_t *ksk;
+    uint64_t *bk_lo, *bk_hi; /* NTT of the two 32-bit limbs of every BK polynomial */
+};
+
+oracle_mk_ctx *oracle_mk_ctx_create(const oracle_params *p, const int64_t *bk, const int32_t *ksk) {
+    if (p->torus_bits != 64 || p->k != 1) return NULL;
+    oracle_mk_ctx *c = (oracle_mk_ctx *)calloc(1, sizeof(*c));
+    c->p = *p;
+    c->bk = bk;
+    c->ksk = ksk;
+    const int N = p->N;
+    const gl_tables *T = gl_get_tables(N);
+    size_t polys = (size_t)p->parties * p->n * 4 * p->l;
+    c->bk_lo = (uint64_t *)malloc(polys * N * sizeof(uint64_t));
+    c->bk_hi = (uint64_t *)malloc(polys * N * sizeof(uint64_t));
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)polys; q++) {
+        uint64_t *lo = c->bk_lo + (size_t)q * N, *hi = c->bk_hi + (size_t)q * N;
+        const int64_t *src = bk + (size_t)q * N;
+        for (int j = 0; j < N; j++) {
+            lo[j] = (uint64_t)src[j] & 0xFFFFFFFFull;
+            hi[j] = gl_from_i64(src[j] >> 32);
+        }
+        gl_ntt_fwd(lo, T);
+        gl_ntt_fwd(hi, T);
+    }
+    return c;
+}
+void oracle_mk_ctx_destroy(oracle_mk_ctx *c) {
+    if (!c) return;
+    free(c->bk_lo);
+    free(c->bk_hi);
+    free(c);
+}
+
+/* tgsw_extern_mul_3gen       J/tgsw_3gen.jl:102-113
+ * acc = [c1 (mask), c0 (body)];  c0' = S g(c0)_l*P1_l + g(c1)_l*P2_l ; c1' = S g(c0)_l*P4_l + g(c1)_l*P3_l */
+static void mk_extern_mul(const oracle_mk_ctx *c, int party, int i, const int64_t *tmp, int64_t *out, int use_schoolbook) {
+    const int N = c->p.N, l = c->p.l;
+    const size_t key_off = ((size_t)party * c->p.n + i) * 4 * l; /* in polynomials */
+    int64_t *dig = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)l * N);
+    int64_t *g_c1 = dig, *g_c0 = dig + (size_t)l * N;
+    oracle_decompose64(tmp, N, l, c->p.Bgbit, g_c1);     /* tmp[0] = c1 (mask) */
+    oracle_decompose64(tmp + N, N, l, c->p.Bgbit, g_c0); /* tmp[1] = c0 (body) */
+    /* which part multiplies which digit set, per output: out[1]=c0' : (g_c0,P1) (g_c1,P2); out[0]=c1' : (g_c0,P4) (g_c1,P3) */
+    const int part_for[2][2] = {{3, 2}, {0, 1}}; /* [out poly][0: g_c0, 1: g_c1] -> part index 0..3 */
+    if (use_schoolbook) {
+        int64_t *prod = (int64_t *)malloc(sizeof(int64_t) * N);
+        memset(out, 0, sizeof(int64_t) * 2 * (size_t)N);
+        for (int o = 0; o < 2; o++)
+            for (int w = 0; w < 2; w++)
+                for (int q = 0; q < l; q++) {
+                    const int64_t *d = (w == 0 ? g_c0 : g_c1) + (size_t)q * N;
+                    const int64_t *row = c->bk + (key_off + (size_t)part_for[o][w] * l + q) * N;
+                    oracle_polymul_schoolbook64(d, row, N, prod);
+                    for (int j = 0; j < N; j++) out[(size_t)o * N + j] = (int64_t)((uint64_t)out[(size_t)o * N + j] + (uint64_t)prod[j]);
+                }
+        free(prod);
+    } else {
+        const gl_tables *T = gl_get_tables(N);
+        uint64_t *d = (uint64_t *)malloc(sizeof(uint64_t) * (2 * (size_t)l + 2) * N);
+        uint64_t *alo = d + 2 * (size_t)l * N, *ahi = alo + N;
+        for (int r = 0; r < 2 * l; r++) {
+            for (int j = 0; j < N; j++) d[(size_t)r * N + j] = gl_from_i64(dig[(size_t)r * N + j]);
+            gl_ntt_fwd(d + (size_t)r * N, T);
+        }
+        for (int o = 0; o < 2; o++) {
+            for (int j = 0; j < N; j++) {
+                uint64_t slo = 0, shi = 0;
+                for (int w = 0; w < 2; w++)
+                    for (int q = 0; q < l; q++) {
+                        uint64_t dv = d[((size_t)(w == 0 ? l : 0) + q) * N + j]; /* g_c0 stored second */
+                        size_t ro = (key_off + (size_t)part_for[o][w] * l + q) * N + j;
+                        slo = gl_add(slo, gl_mul(dv, c->bk_lo[ro]));
+                        shi = gl_add(shi, gl_mul(dv, c->bk_hi[ro]));
+                    }
+                alo[j] = slo;
+                ahi[j] = shi;
+            }
+            gl_ntt_inv(alo, T);
+            gl_ntt_inv(ahi, T);
+            for (int j = 0; j < N; j++)
+                out[(size_t)o * N + j] = (int64_t)((uint64_t)gl_to_centered(alo[j]) + ((uint64_t)gl_to_centered(ahi[j]) << 32));
+        }
+        free(d);
+    }
+    free(dig);
+}
+
+/* mk_mux_rotate_3gen      J/3gen_mk_internals.jl:59-62 */
+void oracle_mk_mux_rotate(const oracle_mk_ctx *c, int32_t party, int32_t i, int32_t barai, int64_t *acc, int use_schoolbook) {
+    const int N = c->p.N;
+    int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * 4 * (size_t)N), *ext = tmp + 2 * (size_t)N;
+    for (int m = 0; m < 2; m++) {
+        oracle_mul_by_monomial64(acc + (size_t)m * N, barai, N, tmp + (size_t)m * N);
+        for (int q = 0; q < N; q++) tmp[(size_t)m * N + q] = (int64_t)((uint64_t)tmp[(size_t)m * N + q] - (uint64_t)acc[(size_t)m * N + q]);
+    }
+    mk_extern_mul(c, party, i, tmp, ext, use_schoolbook);
+    for (int q = 0; q < 2 * N; q++) acc[q] = (int64_t)((uint64_t)acc[q] + (uint64_t)ext[q]);
+    free(tmp);
+}
+
+/* mk_bootstrap_wo_keyswitch_3gen / mk_blind_rotate_and_extract_3gen / mk_blind_rotate_3gen
+ * J/3gen_mk_internals.jl:66-109 ; extraction rlwe_extract_sample_64 J/rlwe.jl:70-74 */
+void oracle_mk_bootstrap_wo_keyswitch(const oracle_mk_ctx *c, int64_t mu, const int32_t *x, int32_t *out, int use_schoolbook) {
+    const int N = c->p.N, n = c->p.n, P = c->p.parties;
+    int32_t barb = oracle_modswitch(x[(size_t)n * P], N);
+    int64_t *acc = (int64_t *)calloc(2 * (size_t)N, sizeof(int64_t));
+    int64_t *tv = (int64_t *)malloc(sizeof(int64_t) * N);
+    for (int j = 0; j < N; j++) tv[j] = mu;
+    oracle_mul_by_monomial64(tv, -barb, N, acc + N);
+    for (int p = 0; p < P; p++) /* parties outer, key index inner */
+        for (int i = 0; i < n; i++) {
+            int32_t bara = oracle_modswitch(x[(size_t)p * n + i], N);
+            if (bara != 0) oracle_mk_mux_rotate(c, p, i, bara, acc, use_schoolbook);
+        }
+    out[0] = oracle_t64tot32(acc[0]);
+    for (int j = 1; j < N; j++) out[j] = oracle_t64tot32((int64_t)(0ull - (uint64_t)acc[N - j]));
+    out[N] = oracle_t64tot32(acc[N]);
+    free(tv);
+    free(acc);
+}
+
+/* mk_keyswitch_3gen       J/mk_internals.jl:730-744 */
+void oracle_mk_keyswitch(const oracle_mk_ctx *c, const int32_t *in, int32_t *out) {
+    const int N = c->p.N, n = c->p.n, P = c->p.parties, t = c->p.ks_t, bb = c->p.ks_basebit;
+    const size_t per_party = (size_t)N * t * ((1 << bb) - 1) * ((size_t)n + 1);
+    int32_t *part = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    uint32_t b = (uint32_t)in[N];
+    for (int p = 0; p < P; p++) {
+        keyswitch_with(c->ksk + (size_t)p * per_party, N, n, t, bb, in, 0, part); /* keyswitch(ks[p], (a, 0)) */
+        memcpy(out + (size_t)p * n, part, sizeof(int32_t) * n);
+        b += (uint32_t)part[n];
+    }
+    out[(size_t)n * P] = (int32_t)b;
+    free(part);
+}
+
+int oracle_mk_gates(const oracle_mk_ctx *c, int op, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                    int32_t *out, size_t count, int use_schoolbook) {
+    const int n = c->p.n, N = c->p.N, P = c->p.parties;
+    const size_t rec = (size_t)n * P + 1;
+    const int64_t MU = (int64_t)1 << 61; /* encode_message64(1, 8)   J/numeric-functions.jl:92-95 */
+    const int32_t E8 = 1 << 29, E4 = 1 << 30;
+    if (op == OR_GATE_NOT || op == OR_GATE_COPY) {
+        for (size_t g = 0; g < count * rec; g++) out[g] = op == OR_GATE_NOT ? (int32_t)(0u - (uint32_t)in0[g]) : in0[g];
+        return 0;
+    }
+    if (!(op == OR_GATE_NAND || op == OR_GATE_OR || op == OR_GATE_AND || op == OR_GATE_XOR || op == OR_GATE_AND3 || op == OR_GATE_MUX))
+        return -1; /* only the gates J/3gen_mk_gates.jl defines */
+    int32_t *res = (int32_t *)malloc(sizeof(int32_t) * count * rec);
+#pragma omp parallel for schedule(dynamic)
+    for (long g = 0; g < (long)count; g++) {
+        int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (2 * rec + (size_t)N + 1));
+        int32_t *t2 = tmp + rec, *u = t2 + rec;
+        const int32_t *x = in0 + g * rec, *y = in1 + g * rec, *z = in2 ? in2 + g * rec : NULL;
+        if (op == OR_GATE_AND3) { /* J/3gen_mk_gates.jl:55-64 */
+            for (size_t q = 0; q < rec; q++) tmp[q] = (int32_t)((uint32_t)x[q] + (uint32_t)y[q] + (uint32_t)z[q]);
+            tmp[rec - 1] = (int32_t)((uint32_t)tmp[rec - 1] - (uint32_t)E4);
+            oracle_mk_bootstrap_wo_keyswitch(c, MU, tmp, u, use_schoolbook);
+            oracle_mk_keyswitch(c, u, res + g * rec);
+        } else if (op == OR_GATE_MUX) { /* J/3gen_mk_gates.jl:133-150: two full ANDs, then linear, no final bootstrap */
+            for (size_t q = 0; q < rec; q++) tmp[q] = (int32_t)((uint32_t)x[q] + (uint32_t)y[q]);
+            tmp[rec - 1] = (int32_t)((uint32_t)tmp[rec - 1] - (uint32_t)E8);
+            oracle_mk_bootstrap_wo_keyswitch(c, MU, tmp, u, use_schoolbook);
+            oracle_mk_keyswitch(c, u, t2);
+            for (size_t q = 0; q < rec; q++) tmp[q] = (int32_t)((uint32_t)z[q] - (uint32_t)x[q]);
+            tmp[rec - 1] = (int32_t)((uint32_t)tmp[rec - 1] - (uint32_t)E8);
+            oracle_mk_bootstrap_wo_keyswitch(c, MU, tmp, u, use_schoolbook);
+            oracle_mk_keyswitch(c, u, tmp);
+            for (size_t q = 0; q < rec; q++) res[g * rec + q] = (int32_t)((uint32_t)tmp[q] + (uint32_t)t2[q]);
+            res[g * rec + rec - 1] = (int32_t)((uint32_t)res[g * rec + rec - 1] + (uint32_t)E8);
+        } else {
+            lin_t L;
+            gate_lin(op, 0, &L);
+            for (size_t q = 0; q < rec; q++) tmp[q] = (int32_t)((uint32_t)L.cx * (uint32_t)x[q] + (uint32_t)L.cy * (uint32_t)y[q]);
+            tmp[rec - 1] = (int32_t)((uint32_t)tmp[rec - 1] + (uint32_t)L.cb);
+            oracle_mk_bootstrap_wo_keyswitch(c, MU, tmp, u, use_schoolbook);
+            oracle_mk_keyswitch(c, u, res + g * rec);
+        }
+        free(tmp);
+    }
+    memcpy(out, res, sizeof(int32_t) * count * rec);
+    free(res);
+    return 0;
+}
+
+/* ============================================================================================
+ * deterministic RNG, key generation, encryption (host side; mirrors the reference constructors
+ * but with OUR OWN random streams -- Julia's MersenneTwister stream is not reproducible here)
+ * ========================================================================================== */
+typedef struct {
+    uint64_t s[4];
+    int have_spare;
+    double spare;
+} rng_t;
+static uint64_t splitmix64(uint64_t *x) {
+    uint64_t z = (*x += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static void rng_init(rng_t *r, uint64_t seed, uint64_t stream) {
+    uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ULL + 0x2545F4914F6CDD1DULL);
+    for (int i = 0; i < 4; i++) r->s[i] = splitmix64(&x);
+    r->have_spare = 0;
+}
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static uint64_t rng_u64(rng_t *r) { /* xoshiro256** */
+    uint64_t *s = r->s, result = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return result;
+}
+static double rng_unit(rng_t *r) { return ((double)(rng_u64(r) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+static double rng_gauss(rng_t *r) { /* Box-Muller */
+    if (r->have_spare) {
+        r->have_spare = 0;
+        return r->spare;
+    }
+    double u = rng_unit(r), v = rng_unit(r), m = sqrt(-2.0 * log(u));
+    r->spare = m * sin(6.283185307179586476925 * v);
+    r->have_spare = 1;
+    return m * cos(6.283185307179586476925 * v);
+}
+static int32_t dtot32(double d) { return (int32_t)(int64_t)trunc(d * 4294967296.0); } /* J/numeric-functions.jl:101-103 */
+static int64_t dtot64(double d) { return (int64_t)trunc(d * 18446744073709551616.0); }  /* :105-107 */
+static int32_t rng_ternary(rng_t *r) { /* rand_negative_binary: P(+-1) = 0.113546097609674   J/numeric-functions.jl:11-13 */
+    double u = rng_unit(r);
+    return u < 0.113546097609674 ? -1 : (u < 2 * 0.113546097609674 ? 1 : 0);
+}
+
+/* exact product of a small-coefficient key polynomial with a torus polynomial */
+static void key_mul32(const int32_t *key, const int32_t *a, int N, int32_t *out) { oracle_polymul_ntt32(key, a, N, out); }
+static void key_mul64(const int64_t *key, const int64_t *a, int N, int64_t *out) { oracle_polymul_ntt64(key, a, N, out); }
+
+/* KeyswitchKey constructor      J/keyswitch.jl:14-41  (noise recentred over the whole table) */
+static void gen_ksk(rng_t *r, const int32_t *in_key, int Nin, const int32_t *out_key, int n, int t, int basebit, double sigma, int32_t *ksk) {
+    const int base = 1 << basebit;
+    size_t cnt = (size_t)Nin * t * (base - 1);
+    double *noise = (double *)malloc(sizeof(double) * cnt), mean = 0;
+    for (size_t q = 0; q < cnt; q++) {
+        noise[q] = rng_gauss(r) * sigma;
+        mean += noise[q];
+    }
+    mean /= (double)cnt;
+    for (size_t q = 0; q < cnt; q++) noise[q] -= mean;
+    for (int i = 0; i < Nin; i++)
+        for (int j = 1; j <= t; j++)
+            for (int h = 1; h < base; h++) {
+                size_t e = (((size_t)i * t + (j - 1)) * (base - 1)) + (h - 1);
+                int32_t *row = ksk + e * ((size_t)n + 1);
+                uint32_t msg = (uint32_t)(in_key[i] * h) << (32 - j * basebit);
+                uint32_t b = msg + (uint32_t)dtot32(noise[e]);
+                for (int q = 0; q < n; q++) {
+                    row[q] = (int32_t)(uint32_t)rng_u64(r);
+                    b += (uint32_t)row[q] * (uint32_t)out_key[q];
+                }
+                row[n] = (int32_t)b;
+            }
+    free(noise);
+}
+
+/* BootstrapKey constructor (coefficient domain)      J/bootstrap.jl:6-15, tgsw_encrypt J/tgsw.jl:88-101,
+ * rlwe_encrypt_zero J/rlwe.jl:79-105, gadget J/tgsw.jl:65-85 */
+void oracle_keygen_sk(const oracle_params *p, uint64_t seed, double sigma_bk, double sigma_ks,
+                      const int32_t *lwe_key_in, int32_t *lwe_key, int32_t *rlwe_key, int32_t *bk, int32_t *ksk) {
+    const int n = p->n, N = p->N, k = p->k, l = p->l, rows = (k + 1) * l;
+    rng_t r;
+    rng_init(&r, seed, 1);
+    for (int i = 0; i < n; i++) lwe_key[i] = lwe_key_in ? lwe_key_in[i] : (int32_t)(rng_u64(&r) & 1);
+    rng_init(&r, seed, 2);
+    for (int i = 0; i < k * N; i++) rlwe_key[i] = (int32_t)(rng_u64(&r) & 1);
+#pragma omp parallel for schedule(dynamic)
+    for (int i = 0; i < n; i++) {
+        rng_t ri;
+        rng_init(&ri, seed, 1000 + (uint64_t)i);
+        int32_t *prod = (int32_t *)malloc(sizeof(int32_t) * N);
+        for (int row = 0; row < rows; row++) {
+            int j = row / l, q = row % l; /* block j, level q (0-based) */
+            int32_t *base = bk + (((size_t)i * rows + row) * (k + 1)) * N;
+            int32_t *body = base + (size_t)k * N;
+            for (int t = 0; t < N; t++) body[t] = dtot32(rng_gauss(&ri) * sigma_bk);
+            for (int m = 0; m < k; m++) {
+                int32_t *a = base + (size_t)m * N;
+                for (int t = 0; t < N; t++) a[t] = (int32_t)(uint32_t)rng_u64(&ri);
+                key_mul32(rlwe_key + (size_t)m * N, a, N, prod);
+                for (int t = 0; t < N; t++) body[t] = (int32_t)((uint32_t)body[t] + (uint32_t)prod[t]);
+            }
+            /* + message * gadget[q] on the constant coefficient of polynomial j */
+            uint32_t g = (uint32_t)lwe_key[i] << (32 - (q + 1) * p->Bgbit);
+            base[(size_t)j * N] = (int32_t)((uint32_t)base[(size_t)j * N] + g);
+        }
+        free(prod);
+    }
+    rng_init(&r, seed, 3);
+    gen_ksk(&r, rlwe_key, k * N, lwe_key, n, p->ks_t, p->ks_basebit, sigma_ks, ksk);
+}
+
+/* 3-gen multi-key key material: flow of 3-gen-mk-tfhe/multikey_3gen.jl:15-30
+ *   CRP_3gen(a_same=true) J/mk_internals.jl:120-137 ; PublicKey J/mk_internals.jl:209-245 ;
+ *   CommonPubKey_3gen :266-298 ; tgsw_encrypt_3gen J/tgsw_3gen.jl:41-95 ; KeyswitchKey J/keyswitch.jl:14-41 */
+void oracle_keygen_mk(const oracle_params *p, uint64_t seed, double sigma_bk, double sigma_ks,
+                      int32_t *lwe_keys, int64_t *rlwe_keys, int64_t *bk, int32_t *ksk) {
+    const int n = p->n, N = p->N, l = p->l, P = p->parties;
+    rng_t r;
+    rng_init(&r, seed, 11);
+    for (int i = 0; i < P * n; i++) lwe_keys[i] = (int32_t)(rng_u64(&r) & 1); /* SecretKey_3gen: binary LWE keys */
+    rng_init(&r, seed, 12);
+    for (int i = 0; i < P * N; i++) rlwe_keys[i] = rng_ternary(&r); /* RLweKey(rng, params, true) */
+    int64_t *crp = (int64_t *)malloc(sizeof(int64_t) * N);
+    int64_t *B = (int64_t *)calloc((size_t)l * N, sizeof(int64_t));
+    int64_t *prod = (int64_t *)malloc(sizeof(int64_t) * N);
+    rng_init(&r, seed, 13);
+    for (int t = 0; t < N; t++) crp[t] = (int64_t)rng_u64(&r); /* one common random polynomial, repeated l times */
+    rng_init(&r, seed, 14);
+    for (int q = 0; q < P; q++) { /* b_q[i] = z_q * a + e ; B[i] = sum_q b_q[i] */
+        key_mul64(rlwe_keys + (size_t)q * N, crp, N, prod);
+        for (int i = 0; i < l; i++)
+            for (int t = 0; t < N; t++)
+                B[(size_t)i * N + t] = (int64_t)((uint64_t)B[(size_t)i * N + t] + (uint64_t)prod[t] + (uint64_t)dtot64(rng_gauss(&r) * sigma_bk));
+    }
+    free(prod);
+#pragma omp parallel for schedule(dynamic) collapse(2)
+    for (int q = 0; q < P; q++)
+        for (int i = 0; i < n; i++) {
+            rng_t ri;
+            rng_init(&ri, seed, 100000 + (uint64_t)q * 10000 + (uint64_t)i);
+            int64_t *r1 = (int64_t *)malloc(sizeof(int64_t) * 3 * (size_t)N), *r2 = r1 + N, *pr = r2 + N;
+            int64_t *key = bk + (((size_t)q * n + i) * 4 * l) * N;
+            int64_t m = lwe_keys[(size_t)q * n + i];
+            for (int lv = 0; lv < l; lv++) {
+                for (int t = 0; t < N; t++) r1[t] = rng_ternary(&ri);
+                for (int t = 0; t < N; t++) r2[t] = rng_ternary(&ri);
+                uint64_t g = (uint64_t)m << (64 - (lv + 1) * p->Bgbit);
+                int64_t *P1 = key + ((size_t)0 * l + lv) * N, *P2 = key + ((size_t)1 * l + lv) * N;
+                int64_t *P3 = key + ((size_t)2 * l + lv) * N, *P4 = key + ((size_t)3 * l + lv) * N;
+                key_mul64(r1, B + (size_t)lv * N, N, pr);
+                for (int t = 0; t < N; t++) P1[t] = (int64_t)((uint64_t)pr[t] + (uint64_t)dtot64(rng_gauss(&ri) * sigma_bk));
+                P1[0] = (int64_t)((uint64_t)P1[0] + g);
+                key_mul64(r2, B + (size_t)lv * N, N, pr);
+                for (int t = 0; t < N; t++) P2[t] = (int64_t)((uint64_t)pr[t] + (uint64_t)dtot64(rng_gauss(&ri) * sigma_bk));
+                key_mul64(r2, crp, N, pr);
+                for (int t = 0; t < N; t++) P3[t] = (int64_t)((uint64_t)pr[t] + (uint64_t)dtot64(rng_gauss(&ri) * sigma_bk));
+                P3[0] = (int64_t)((uint64_t)P3[0] + g);
+                key_mul64(r1, crp, N, pr);
+                for (int t = 0; t < N; t++) P4[t] = (int64_t)((uint64_t)pr[t] + (uint64_t)dtot64(rng_gauss(&ri) * sigma_bk));
+            }
+            free(r1);
+        }
+    const size_t per_party = (size_t)N * p->ks_t * ((1 << p->ks_basebit) - 1) * ((size_t)n + 1);
+    int32_t *z32 = (int32_t *)malloc(sizeof(int32_t) * N);
+    for (int q = 0; q < P; q++) {
+        rng_init(&r, seed, 20 + (uint64_t)q);
+        for (int t = 0; t < N; t++) z32[t] = (int32_t)rlwe_keys[(size_t)q * N + t];
+        gen_ksk(&r, z32, N, lwe_keys + (size_t)q * n, n, p->ks_t, p->ks_basebit, sigma_ks, ksk + (size_t)q * per_party);
+    }
+    free(z32);
+    free(crp);
+    free(B);
+}
+
+/* lwe_encrypt: b = mu + e + <a, s>      J/lwe.jl:38-43 */
+void oracle_lwe_encrypt(const int32_t *key, int32_t n, int32_t mu, double sigma, uint64_t seed, uint64_t idx, int32_t *rec) {
+    rng_t r;
+    rng_init(&r, seed, 0x10000000ULL + idx);
+    uint32_t b = (uint32_t)mu + (uint32_t)dtot32(rng_gauss(&r) * sigma);
+    for (int i = 0; i < n; i++) {
+        rec[i] = (int32_t)(uint32_t)rng_u64(&r);
+        b += (uint32_t)rec[i] * (uint32_t)key[i];
+    }
+    rec[n] = (int32_t)b;
+}
+/* lwe_phase = b - <a, s>      J/lwe.jl:59 */
+int32_t oracle_lwe_phase(const int32_t *key, int32_t n, const int32_t *rec) {
+    uint32_t ph = (uint32_t)rec[n];
+    for (int i = 0; i < n; i++) ph -= (uint32_t)rec[i] * (uint32_t)key[i];
+    return (int32_t)ph;
+}
+/* mk_encrypt_3gen      J/mk_api.jl:519-536 ; mk_lwe_phase J/mk_internals.jl:85-91 */
+void oracle_mk_lwe_encrypt(const int32_t *keys, int32_t n, int32_t P, int32_t mu, double sigma, uint64_t seed, uint64_t idx, int32_t *rec) {
+    oracle_lwe_encrypt(keys, n * P, mu, sigma, seed, idx, rec);
+}
+int32_t oracle_mk_lwe_phase(const int32_t *keys, int32_t n, int32_t P, const int32_t *rec) { return oracle_lwe_phase(keys, n * P, rec); }
