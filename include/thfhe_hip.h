@@ -1,0 +1,127 @@
+/*
+ * thfhe_hip.h -- C ABI of libthfhe_hip.so, the MI355X-native gate-bootstrapping engine.
+ *
+ * Drop-in boundary for ONE hot path of Animesh005/Torus-FHE: bootstrapped gate evaluation
+ * (blind rotate = n x CMux, sample extraction, key switching).  Reference interfaces replaced
+ * (paths relative to the reference tree, J/ = 3-gen-mk-tfhe/src/):
+ *
+ *   thfhe_gates                      <- gate_nand/or/and/xor/xnor/nor/andny/andyn/orny/oryn/mux/not  J/gates.jl:15-177
+ *                                       == libtfhe's extern "C" bootsNAND/AND/OR/XOR/.../MUX/NOT that the C++ side
+ *                                       calls (src/KNN_medical_data.cpp:130,142-151,227,388-396; src/Convert.cpp:31)
+ *   thfhe_bootstrap                  <- bootstrap(bk, ks, mu, x)                    J/bootstrap.jl:98-101
+ *   thfhe_bootstrap_wo_keyswitch     <- bootstrap_wo_keyswitch(bk, mu, x)           J/bootstrap.jl:75-88
+ *   thfhe_keyswitch                  <- keyswitch(ks, sample)                       J/keyswitch.jl:45-80
+ *   thfhe_ctx_create                 <- BootstrapKey(...) forward_transform step    J/bootstrap.jl:6-15 (key -> transformed key)
+ *                                       + KeyswitchKey table upload                 J/keyswitch.jl:7-42
+ *   thfhe_mk_*                       <- mk_bootstrap_3gen / mk_gate_*_3gen          J/3gen_mk_internals.jl:99-116, J/3gen_mk_gates.jl:8-150
+ *   bootsNAND ... (tfhe_shim.h)      <- the libtfhe symbols themselves (struct-compatible shims)
+ *
+ * All entry points are plain C: pointers + sizes, no C++/torch types.  Return value: 0 on success,
+ * negative THFHE_E_* on failure (thfhe_last_error() gives a message).  There is NO CPU fallback: if
+ * no HIP device is usable every compute call fails with THFHE_E_NO_DEVICE.
+ *
+ * Data layouts (little-endian, row-major, innermost last):
+ *   LWE record                  int32[n+1]   = a[0..n), b                       (LweSample, J/lwe.jl:21-29)
+ *   extracted LWE record        int32[N+1]
+ *   bk_coeff  (single key)      int32[n][(k+1)l][k+1][N], row r = j*l + p (block j, level p) -- libtfhe's
+ *                               TGswSample.all_sample order; coefficient domain (Torus32)
+ *   ksk       (single key)      int32[N][t][base-1][n+1], entry (i, j, h-1) = KS[h, j, i]    (J/keyswitch.jl:35-38)
+ *   MK record (P parties)       int32[P*n+1] = a[p*n + i], b                     (MKLweSample, J/mk_internals.jl:23-37)
+ *   mk bk_coeff                 int64[P][n][4][l][N]  (part_1..part_4, level)    (TGswSample_3gen, J/tgsw_3gen.jl:3-20)
+ *   mk ksk                      int32[P][N][t][base-1][n+1]
+ */
+#ifndef THFHE_HIP_H
+#define THFHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct thfhe_params {
+    int32_t n;          /* LWE dimension                (lwe_size, J/api.jl:4-21)                     */
+    int32_t N;          /* ring degree                  (rlwe_polynomial_degree); 1024 supported      */
+    int32_t k;          /* RLWE mask size; 1 supported                                                 */
+    int32_t l;          /* gadget decomposition length  (bs_decomp_length); 1..4                       */
+    int32_t Bgbit;      /* log2 gadget base             (bs_log2_base); l*Bgbit <= 32, Bgbit <= 10     */
+    int32_t ks_t;       /* key-switch length            (ks_decomp_length)                             */
+    int32_t ks_basebit; /* key-switch log2 base         (ks_log2_base)                                 */
+    int32_t torus_bits; /* 32 = Torus32 ring (single key), 64 = Torus64 ring (3-gen multi-key)         */
+    int32_t parties;    /* 1 = single key                                                              */
+} thfhe_params;
+
+/* gate opcodes (J/gates.jl; J/3gen_mk_gates.jl for AND3) */
+enum thfhe_gate {
+    THFHE_NAND = 0, THFHE_OR = 1, THFHE_AND = 2, THFHE_XOR = 3, THFHE_XNOR = 4, THFHE_NOR = 5,
+    THFHE_ANDNY = 6, THFHE_ANDYN = 7, THFHE_ORNY = 8, THFHE_ORYN = 9, THFHE_MUX = 10,
+    THFHE_NOT = 11, THFHE_COPY = 12, THFHE_AND3 = 13
+};
+
+enum thfhe_error {
+    THFHE_OK = 0, THFHE_E_INVALID = -1, THFHE_E_UNSUPPORTED = -2, THFHE_E_NO_DEVICE = -3,
+    THFHE_E_HIP = -4, THFHE_E_NOMEM = -5
+};
+
+typedef struct thfhe_ctx thfhe_ctx;
+
+const char *thfhe_last_error(void);
+int thfhe_device_count(void);
+
+/* Upload + transform the keys to device `device`.  bk_coeff / ksk are HOST pointers, borrowed only
+ * for the duration of the call. */
+int thfhe_ctx_create(const thfhe_params *params, const int32_t *bk_coeff, const int32_t *ksk, int device,
+                     thfhe_ctx **out);
+void thfhe_ctx_destroy(thfhe_ctx *ctx);
+int thfhe_ctx_params(const thfhe_ctx *ctx, thfhe_params *out);
+
+/* ---- host-buffer API: the drop-in level.  in0/in1/in2/out are HOST arrays of `count` records.  `out` may alias
+ * an input (the reference's callers do, src/KNN_medical_data.cpp:256,395).  Thread-safe per ctx. */
+int thfhe_gates(thfhe_ctx *ctx, int op, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                int32_t *out, size_t count);
+int thfhe_bootstrap(thfhe_ctx *ctx, int32_t mu, const int32_t *x, int32_t *out, size_t count);
+int thfhe_bootstrap_wo_keyswitch(thfhe_ctx *ctx, int32_t mu, const int32_t *x, int32_t *out_N1, size_t count);
+int thfhe_keyswitch(thfhe_ctx *ctx, const int32_t *in_N1, int32_t *out, size_t count);
+
+/* ---- device-buffer API: records already resident in HBM (what bench.py times).  Pointers come from
+ * thfhe_dev_alloc (or any hipMalloc in this process).  Calls enqueue on the context's stream and
+ * return; thfhe_sync waits. */
+void *thfhe_dev_alloc(thfhe_ctx *ctx, size_t bytes);
+void thfhe_dev_free(thfhe_ctx *ctx, void *p);
+int thfhe_copy_h2d(thfhe_ctx *ctx, void *dst, const void *src, size_t bytes);
+int thfhe_copy_d2h(thfhe_ctx *ctx, void *dst, const void *src, size_t bytes);
+int thfhe_reserve(thfhe_ctx *ctx, size_t max_count); /* pre-size the workspace (no allocation afterwards) */
+int thfhe_gates_dev(thfhe_ctx *ctx, int op, const int32_t *d_in0, const int32_t *d_in1, const int32_t *d_in2,
+                    int32_t *d_out, size_t count);
+int thfhe_sync(thfhe_ctx *ctx);
+
+/* Per-kernel device timing: when enabled, every *_dev call brackets each kernel with HIP events on the
+ * context's stream.  After thfhe_sync, thfhe_last_timings returns milliseconds of the most recent call:
+ * ms[0] = prologue (linear part + mod-switch), ms[1] = blind rotate, ms[2] = key switch, ms[3] = total. */
+int thfhe_set_profiling(thfhe_ctx *ctx, int enabled);
+int thfhe_last_timings(thfhe_ctx *ctx, float ms[4]);
+
+/* ---- 3-gen multi-key (Torus64 ring) --------------------------------------------------------------- */
+typedef struct thfhe_mk_ctx thfhe_mk_ctx;
+int thfhe_mk_ctx_create(const thfhe_params *params, const int64_t *bk_coeff, const int32_t *ksk, int device,
+                        thfhe_mk_ctx **out);
+void thfhe_mk_ctx_destroy(thfhe_mk_ctx *ctx);
+int thfhe_mk_gates(thfhe_mk_ctx *ctx, int op, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                   int32_t *out, size_t count);
+int thfhe_mk_bootstrap(thfhe_mk_ctx *ctx, int64_t mu, const int32_t *x, int32_t *out, size_t count);
+void *thfhe_mk_dev_alloc(thfhe_mk_ctx *ctx, size_t bytes);
+void thfhe_mk_dev_free(thfhe_mk_ctx *ctx, void *p);
+int thfhe_mk_copy_h2d(thfhe_mk_ctx *ctx, void *dst, const void *src, size_t bytes);
+int thfhe_mk_copy_d2h(thfhe_mk_ctx *ctx, void *dst, const void *src, size_t bytes);
+int thfhe_mk_reserve(thfhe_mk_ctx *ctx, size_t max_count);
+int thfhe_mk_gates_dev(thfhe_mk_ctx *ctx, int op, const int32_t *d_in0, const int32_t *d_in1,
+                       const int32_t *d_in2, int32_t *d_out, size_t count);
+int thfhe_mk_sync(thfhe_mk_ctx *ctx);
+int thfhe_mk_set_profiling(thfhe_mk_ctx *ctx, int enabled);
+int thfhe_mk_last_timings(thfhe_mk_ctx *ctx, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THFHE_HIP_H */

@@ -1,0 +1,153 @@
+// lane_emu.cpp -- TEST INFRASTRUCTURE ONLY (never linked into libthfhe_hip.so, never reachable from the
+// product API).  Replays the per-lane segments of torus-fhe_amd/csrc/thfhe_lane.h on the host, looping
+// over the 64 lanes of a wavefront between the wave-level LDS exchanges, so the kernel's index algebra
+// and FP64 exactness margin are checked against the CPU oracle in the `-m "not gpu"` suite.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../torus-fhe_amd/csrc/thfhe_lane.h"
+
+using namespace thfhe;
+
+namespace {
+struct Wave {
+    cplx T1[512], T2[64];
+    cplx xbuf[kXbufSlots];
+    Wave() { make_twiddles_1024(T1, T2); }
+    void fwd(cplx (*z)[8]) {  // z[lane][8]
+        for (int l = 0; l < 64; l++) fwd_seg1(l, z[l], xbuf, T1);
+        for (int l = 0; l < 64; l++) fwd_seg2_ld(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) fwd_seg2_st(l, z[l], xbuf, T2);
+        for (int l = 0; l < 64; l++) fwd_seg3(l, z[l], xbuf);
+    }
+    void inv(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) inv_seg1(l, z[l], xbuf, T2);
+        for (int l = 0; l < 64; l++) inv_seg2_ld(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) inv_seg2_st(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) inv_seg3(l, z[l], xbuf, T1);
+    }
+};
+}  // namespace
+
+extern "C" {
+
+// coefficient-domain key polynomials -> spectral layout [poly][limb][m][lane], scaled by 1/512
+void emu_transform_key_polys(const int32_t *polys, int64_t npolys, double *spec /* npolys*2*512*2 doubles */) {
+    Wave w;
+    static cplx zlo[64][8], zhi[64][8];
+    for (int64_t q = 0; q < npolys; q++) {
+        for (int l = 0; l < 64; l++) key_limbs_to_z(l, polys + q * 1024, zlo[l], zhi[l]);
+        w.fwd(zlo);
+        w.fwd(zhi);
+        cplx *out = reinterpret_cast<cplx *>(spec) + q * 2 * 512;
+        for (int l = 0; l < 64; l++)
+            for (int m = 0; m < 8; m++) {
+                out[m * 64 + l] = cplx{zlo[l][m].re * (1.0 / 512), zlo[l][m].im * (1.0 / 512)};
+                out[512 + m * 64 + l] = cplx{zhi[l][m].re * (1.0 / 512), zhi[l][m].im * (1.0 / 512)};
+            }
+    }
+}
+
+// exact negacyclic product of a small-coefficient polynomial with a Torus32 polynomial, via the lane code.
+// Also returns the worst distance of any inverse-transform output from an integer (exactness margin).
+double emu_polymul(const int32_t *small, const int32_t *b, int32_t *out) {
+    Wave w;
+    std::vector<double> spec(2 * 512 * 2);
+    emu_transform_key_polys(b, 1, spec.data());
+    const cplx *B = reinterpret_cast<const cplx *>(spec.data());
+    static cplx z[64][8], slo[64][8], shi[64][8];
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) z[l][m] = cplx{(double)small[l + 64 * m], (double)small[l + 64 * m + 512]};
+    w.fwd(z);
+    memset(slo, 0, sizeof(slo));
+    memset(shi, 0, sizeof(shi));
+    for (int l = 0; l < 64; l++) {
+        mac8(l, slo[l], z[l], B);
+        mac8(l, shi[l], z[l], B + 512);
+    }
+    w.inv(slo);
+    w.inv(shi);
+    double worst = 0;
+    std::vector<int32_t> acc(1024, 0);
+    for (int l = 0; l < 64; l++) {
+        for (int m = 0; m < 8; m++)
+            for (double v : {slo[l][m].re, slo[l][m].im, shi[l][m].re, shi[l][m].im}) {
+                double d = v - __builtin_rint(v);
+                if (d < 0) d = -d;
+                if (d > worst) worst = d;
+            }
+        acc_update16(l, acc.data(), slo[l], shi[l]);
+    }
+    memcpy(out, acc.data(), sizeof(int32_t) * 1024);
+    return worst;
+}
+
+// one CMux on acc[2][1024] with the spectral key of index i (bk_spec laid out by emu_transform_key_polys over
+// the coefficient table [n][2l][2][1024], i.e. poly index ((i*2l + r)*2 + c)).   Mirrors blind_rotate_kernel.
+void emu_mux_rotate(const double *bk_spec, int l_levels, int Bgbit, int i, int barai, int32_t *acc) {
+    Wave w;
+    const cplx *BK = reinterpret_cast<const cplx *>(bk_spec);
+    const int rows = 2 * l_levels;
+    const uint32_t offset = decomp_offset32(l_levels, Bgbit);
+    const int a2n = barai & 2047;
+    static cplx S[64][2][2][8], z[64][8];
+    static uint32_t t[64][16];
+    memset(S, 0, sizeof(S));
+    for (int j = 0; j < 2; j++) {
+        for (int l = 0; l < 64; l++) load_rotated16(l, acc + j * 1024, a2n, offset, t[l]);
+        for (int p = 1; p <= l_levels; p++) {
+            for (int l = 0; l < 64; l++) digits_to_z(t[l], p, Bgbit, z[l]);
+            w.fwd(z);
+            int r = j * l_levels + (p - 1);
+            for (int l = 0; l < 64; l++)
+                for (int c = 0; c < 2; c++)
+                    for (int h = 0; h < 2; h++) mac8(l, S[l][c][h], z[l], BK + bk_spec_index(i, r, c, h, rows));
+        }
+    }
+    for (int c = 0; c < 2; c++) {
+        static cplx lo[64][8], hi[64][8];
+        for (int l = 0; l < 64; l++) {
+            memcpy(lo[l], S[l][c][0], sizeof(lo[l]));
+            memcpy(hi[l], S[l][c][1], sizeof(hi[l]));
+        }
+        w.inv(lo);
+        w.inv(hi);
+        for (int l = 0; l < 64; l++) acc_update16(l, acc + c * 1024, lo[l], hi[l]);
+    }
+}
+
+// whole blind rotation + extraction of one job (bara[n], barb given), mirrors the kernel's control flow
+void emu_blind_rotate(const double *bk_spec, int n, int l_levels, int Bgbit, const int32_t *bara, int barb, int32_t mu,
+                      int32_t *out /* 1025 */) {
+    std::vector<int32_t> acc(2048);
+    for (int l = 0; l < 64; l++) acc_init16(l, acc.data(), acc.data() + 1024, barb, mu);
+    for (int i = 0; i < n; i++)
+        if (bara[i] != 0) emu_mux_rotate(bk_spec, l_levels, Bgbit, i, bara[i], acc.data());
+    for (int l = 0; l < 64; l++) extract16(l, acc.data(), acc.data() + 1024, out);
+}
+}
+
+extern "C" {
+// debug/unit-test entry points: raw transforms.  zin: 512 complex in natural order j (z_j = p_j + i p_{j+512});
+// out[lane][m] complex in register order.
+void emu_fwd_raw(const double *zin, double *out) {
+    Wave w;
+    static cplx z[64][8];
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) z[l][m] = cplx{zin[2 * (l + 64 * m)], zin[2 * (l + 64 * m) + 1]};
+    w.fwd(z);
+    memcpy(out, z, sizeof(z));
+}
+void emu_inv_raw(const double *in, double *zout) {
+    Wave w;
+    static cplx z[64][8];
+    memcpy(z, in, sizeof(z));
+    w.inv(z);
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) {
+            zout[2 * (l + 64 * m)] = z[l][m].re;
+            zout[2 * (l + 64 * m) + 1] = z[l][m].im;
+        }
+}
+}

@@ -1,0 +1,60 @@
+// thfhe_common.h -- shared host/device helpers of libthfhe_hip.so (error plumbing, wave-level transform drivers).
+#ifndef THFHE_COMMON_H
+#define THFHE_COMMON_H
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/thfhe_hip.h"
+#include "thfhe_lane.h"
+
+namespace thfhe {
+
+constexpr int kOpIdentity = 100;  // internal opcode: tmp = x (plain bootstrap of a sample)
+
+int thfhe_fail(int code, const char *msg);
+int thfhe_fail_hip(hipError_t e, const char *what);
+
+inline int ilog2(int x) {
+    int l = 0;
+    while ((1 << l) < x) l++;
+    return l;
+}
+
+#define THFHE_HIP(expr)                                                    \
+    do {                                                                   \
+        hipError_t thfhe_e_ = (expr);                                      \
+        if (thfhe_e_ != hipSuccess) return ::thfhe::thfhe_fail_hip(thfhe_e_, #expr); \
+    } while (0)
+
+#if defined(__HIPCC__)
+// Wave-level ordering point between two LDS segments.  One wavefront's DS instructions execute in issue order,
+// so no hardware barrier is needed -- this only stops the compiler from moving LDS accesses across the exchange.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// forward / inverse folded negacyclic transform of the 8 points each lane holds (see thfhe_lane.h)
+__device__ __forceinline__ void wave_fft_fwd(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const cplx *T2) {
+    wave_sync();
+    fwd_seg1(lane, z, xb, T1);
+    wave_sync();
+    fwd_seg2_ld(lane, z, xb);
+    fwd_seg2_st(lane, z, xb, T2);
+    wave_sync();
+    fwd_seg3(lane, z, xb);
+}
+__device__ __forceinline__ void wave_fft_inv(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const cplx *T2) {
+    wave_sync();
+    inv_seg1(lane, z, xb, T2);
+    wave_sync();
+    inv_seg2_ld(lane, z, xb);
+    inv_seg2_st(lane, z, xb);
+    wave_sync();
+    inv_seg3(lane, z, xb, T1);
+}
+#endif
+
+}  // namespace thfhe
+#endif

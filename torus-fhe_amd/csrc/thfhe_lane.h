@@ -1,0 +1,279 @@
+// thfhe_lane.h -- lane-level arithmetic of the MI355X blind-rotate engine.
+//
+// One 64-lane wavefront owns one bootstrapping job.  Every function here is the code ONE LANE runs
+// between two wave-level LDS exchanges ("segments").  The HIP kernels (thfhe_kernels.hip) call the
+// segments back to back with a wave-scope fence in between; tests/emu/lane_emu.cpp (test-only, never
+// linked into libthfhe_hip.so) replays the same segments on the host, looping over the 64 lanes, so
+// the index algebra below is unit-tested against the CPU oracle without a GPU.
+//
+// Transform.  A real polynomial p of degree N = 1024 (mod X^N+1) is folded into N/2 = 512 complex
+// points z_j = p_j + i p_{j+512} and evaluated at the roots x_k = zeta^(4k+1), zeta = exp(i pi/N):
+//     P_k = sum_j z_j zeta^j w^(jk),   w = exp(2 pi i / 512)
+// (the reference does the same folding with the opposite sign convention, 3-gen-mk-tfhe/src/
+// polynomials.jl:208-214; the convention is internal because the bootstrapping key is transformed by
+// this very code).  512 = 8*8*8: three in-register radix-8 passes, two LDS transposes per transform.
+// With j = j0 + 8 j1 + 64 j2 and k = k0 + 8 k1 + 64 k2:
+//     pass 1: DFT8 over j2 of z*C[j2]          (C[m] = zeta^(64 m), wave-uniform constants)
+//             twiddle T1[k0][lane] = zeta^(lane (4 k0 + 1)),  lane = j0 + 8 j1   (merges the twist)
+//     pass 2: DFT8 over j1, twiddle T2[k1][j0] = exp(2 pi i j0 k1 / 64)
+//     pass 3: DFT8 over j0          -> lane (k1 + 8 k0), register k2 holds P[k0 + 8 k1 + 64 k2]
+// The inverse runs the three passes backwards with conjugated twiddles; its 1/512 is folded into the
+// bootstrapping-key spectra.  Spectra never leave this register order, so no permutation pass exists.
+//
+// Exactness.  Torus32 key coefficients are split into two balanced 16-bit limbs; digits are
+// |d| <= 2^(Bgbit-1).  Each limb product sum is an integer of magnitude < 2^37 computed in FP64 with
+// worst-case rounding error < 2^-7, so rounding to nearest recovers it exactly
+// and lo + (hi << 16) mod 2^32 equals the reference's exact product (tgsw_extern_mul_wo_FFT,
+// 3-gen-mk-tfhe/src/tgsw.jl:152-156).
+#ifndef THFHE_LANE_H
+#define THFHE_LANE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define THFHE_FN __host__ __device__ __forceinline__
+#else
+#define THFHE_FN inline __attribute__((always_inline))
+#endif
+
+namespace thfhe {
+
+constexpr int kLanes = 64;
+constexpr int kXbufSlots = 8 * 72;  // padded transpose buffer, in complex slots (9216 B)
+
+struct alignas(16) cplx {
+    double re, im;
+};
+
+THFHE_FN cplx cmul(cplx a, cplx b) { return cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+THFHE_FN cplx cmul_conj(cplx a, cplx b) {  // a * conj(b)
+    return cplx{a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im};
+}
+THFHE_FN cplx cadd(cplx a, cplx b) { return cplx{a.re + b.re, a.im + b.im}; }
+THFHE_FN cplx csub(cplx a, cplx b) { return cplx{a.re - b.re, a.im - b.im}; }
+// multiply by s*i (s = +1 / -1)
+template <int S>
+THFHE_FN cplx mul_si(cplx a) {
+    return S > 0 ? cplx{-a.im, a.re} : cplx{a.im, -a.re};
+}
+
+// C[m] = exp(i pi m / 16), m = 0..7  (zeta^(64 m) for N = 1024)
+#define THFHE_C_RE(m) ((m) == 0 ? 1.0 : (m) == 1 ? 0.98078528040323044913 : (m) == 2 ? 0.92387953251128675613 : (m) == 3 ? 0.83146961230254523708 : (m) == 4 ? 0.70710678118654752440 : (m) == 5 ? 0.55557023301960222474 : (m) == 6 ? 0.38268343236508977173 : 0.19509032201612826785)
+#define THFHE_C_IM(m) ((m) == 0 ? 0.0 : (m) == 1 ? 0.19509032201612826785 : (m) == 2 ? 0.38268343236508977173 : (m) == 3 ? 0.55557023301960222474 : (m) == 4 ? 0.70710678118654752440 : (m) == 5 ? 0.83146961230254523708 : (m) == 6 ? 0.92387953251128675613 : 0.98078528040323044913)
+
+// 8-point DFT, natural order in and out:  y[k] <- sum_m y[m] exp(S * 2 pi i m k / 8)
+template <int S>
+THFHE_FN void dft8(cplx (&y)[8]) {
+    constexpr double R = 0.70710678118654752440;
+    // even half: DFT4 of (y0, y2, y4, y6)
+    cplx t0 = cadd(y[0], y[4]), t1 = csub(y[0], y[4]);
+    cplx t2 = cadd(y[2], y[6]), t3 = mul_si<S>(csub(y[2], y[6]));
+    cplx e0 = cadd(t0, t2), e1 = cadd(t1, t3), e2 = csub(t0, t2), e3 = csub(t1, t3);
+    // odd half: DFT4 of (y1, y3, y5, y7)
+    cplx u0 = cadd(y[1], y[5]), u1 = csub(y[1], y[5]);
+    cplx u2 = cadd(y[3], y[7]), u3 = mul_si<S>(csub(y[3], y[7]));
+    cplx o0 = cadd(u0, u2), o1 = cadd(u1, u3), o2 = csub(u0, u2), o3 = csub(u1, u3);
+    // w^1 = (1 + S i)/sqrt2,  w^2 = S i,  w^3 = (-1 + S i)/sqrt2
+    cplx p1 = S > 0 ? cplx{o1.re - o1.im, o1.re + o1.im} : cplx{o1.re + o1.im, o1.im - o1.re};
+    cplx p3 = S > 0 ? cplx{-o3.re - o3.im, o3.re - o3.im} : cplx{o3.im - o3.re, -o3.re - o3.im};
+    cplx q2 = mul_si<S>(o2);
+    y[0] = cadd(e0, o0);
+    y[4] = csub(e0, o0);
+    y[1] = cplx{e1.re + R * p1.re, e1.im + R * p1.im};
+    y[5] = cplx{e1.re - R * p1.re, e1.im - R * p1.im};
+    y[2] = cadd(e2, q2);
+    y[6] = csub(e2, q2);
+    y[3] = cplx{e3.re + R * p3.re, e3.im + R * p3.im};
+    y[7] = cplx{e3.re - R * p3.re, e3.im - R * p3.im};
+}
+
+// ---- transpose-buffer slot maps (complex slots; conflict-free for ds_read/write_b128) ----
+THFHE_FN int xs_a(int k0, int lane) { return k0 * 72 + lane; }                              // (k0 ; j0 + 8 j1)
+THFHE_FN int xs_b(int j1, int lane) { return (lane >> 3) * 72 + j1 * 8 + (lane & 7); }      // lane = j0 + 8 k0
+THFHE_FN int xs_c(int k1, int lane) { return (lane >> 3) * 72 + k1 * 9 + (lane & 7); }      // lane = j0 + 8 k0
+THFHE_FN int xs_d(int j0, int lane) { return (lane >> 3) * 72 + (lane & 7) * 9 + j0; }      // lane = k1 + 8 k0
+
+// ---- forward transform, three segments -------------------------------------------------------------
+// z[m] on entry: folded coefficients (p[lane + 64 m], p[lane + 64 m + 512])
+THFHE_FN void fwd_seg1(int lane, cplx (&z)[8], cplx *xbuf, const cplx *T1) {
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+    dft8<+1>(z);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) xbuf[xs_a(k0, lane)] = cmul(z[k0], T1[k0 * 64 + lane]);
+}
+// segment 2 is split into its load half and its compute+store half: on the GPU all lanes of the wave
+// finish the loads before any lane stores (the DFT needs all eight inputs), the emulator needs the split.
+THFHE_FN void fwd_seg2_ld(int lane, cplx (&z)[8], const cplx *xbuf) {
+#pragma unroll
+    for (int j1 = 0; j1 < 8; j1++) z[j1] = xbuf[xs_b(j1, lane)];
+}
+THFHE_FN void fwd_seg2_st(int lane, cplx (&z)[8], cplx *xbuf, const cplx *T2) {
+    dft8<+1>(z);
+    xbuf[xs_c(0, lane)] = z[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) xbuf[xs_c(k1, lane)] = cmul(z[k1], T2[k1 * 8 + (lane & 7)]);
+}
+THFHE_FN void fwd_seg3(int lane, cplx (&z)[8], const cplx *xbuf) {
+#pragma unroll
+    for (int j0 = 0; j0 < 8; j0++) z[j0] = xbuf[xs_d(j0, lane)];
+    dft8<+1>(z);
+}
+
+// ---- inverse transform (unnormalised: returns 512 * p), three segments ------------------------------
+THFHE_FN void inv_seg1(int lane, cplx (&z)[8], cplx *xbuf, const cplx *T2) {
+    dft8<-1>(z);
+    xbuf[xs_d(0, lane)] = z[0];
+#pragma unroll
+    for (int j0 = 1; j0 < 8; j0++) xbuf[xs_d(j0, lane)] = cmul_conj(z[j0], T2[j0 * 8 + (lane & 7)]);
+}
+THFHE_FN void inv_seg2_ld(int lane, cplx (&z)[8], const cplx *xbuf) {
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) z[k1] = xbuf[xs_c(k1, lane)];
+}
+THFHE_FN void inv_seg2_st(int lane, cplx (&z)[8], cplx *xbuf) {
+    dft8<-1>(z);
+#pragma unroll
+    for (int j1 = 0; j1 < 8; j1++) xbuf[xs_b(j1, lane)] = z[j1];
+}
+THFHE_FN void inv_seg3(int lane, cplx (&z)[8], const cplx *xbuf, const cplx *T1) {
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) z[k0] = cmul_conj(xbuf[xs_a(k0, lane)], T1[k0 * 64 + lane]);
+    dft8<-1>(z);
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+}
+
+// ---- integer helpers ---------------------------------------------------------------------------------
+// coefficient q of X^a * p - p for p in LDS, a in [0, 2N)          (mul_by_monomial, J/rlwe.jl:130-131)
+THFHE_FN uint32_t rot_minus_self32(const int32_t *p, int q, int a2n, int N) {
+    int e = (q - a2n) & (2 * N - 1);
+    uint32_t r = (uint32_t)p[e & (N - 1)];
+    if (e & N) r = 0u - r;
+    return r - (uint32_t)p[q];
+}
+// signed gadget digit of (v = coefficient + offset)                   (decompose, J/tgsw.jl:112-138)
+THFHE_FN double digit32(uint32_t v, int shift, uint32_t mask, int32_t half) {
+    return (double)((int32_t)((v >> shift) & mask) - half);
+}
+THFHE_FN uint32_t decomp_offset32(int l, int Bgbit) {
+    uint32_t off = 0;
+    for (int p = 1; p <= l; p++) off += (1u << (Bgbit - 1)) << (32 - p * Bgbit);
+    return off;
+}
+// round-to-nearest of x (|x| < 2^51) as a wrapping 32-bit integer: add 1.5*2^52, keep the low mantissa word
+THFHE_FN uint32_t round_lo32(double x) {
+    double y = x + 6755399441055744.0;
+    uint64_t b;
+    __builtin_memcpy(&b, &y, 8);
+    return (uint32_t)b;
+}
+// balanced 16-bit limb split of a Torus32 word: v = lo + 65536 * hi, lo in [-2^15, 2^15)
+THFHE_FN void split_limbs32(int32_t v, double &lo, double &hi) {
+    int32_t l = (int32_t)(int16_t)(uint16_t)v;
+    int32_t h = (int32_t)(((int64_t)v - l) >> 16);
+    lo = (double)l;
+    hi = (double)h;
+}
+
+// mod-switch to Z_2N:  decode_message(x, 2N)                           (J/numeric-functions.jl:70-73)
+THFHE_FN int32_t modswitch2n(int32_t x, int log2_2n) {
+    int32_t y = (int32_t)((uint32_t)x + (1u << (32 - log2_2n - 1)));
+    return y >> (32 - log2_2n);
+}
+
+
+// ---- CMux building blocks (single key, Torus32 ring, k = 1) ----------------------------------------
+// Spectral bootstrapping key: [i][row r = j*l + p][column c][limb h][slot m][lane] complex, i.e. one
+// coalesced 1 KiB line per (i, r, c, h, m); 8 KiB per limb polynomial ("8 B per coefficient" per limb).
+THFHE_FN size_t bk_spec_index(int i, int r, int c, int h, int rows) {
+    return ((((size_t)i * rows + r) * 2 + c) * 2 + h) * 512;  // + m*64 + lane
+}
+
+// t[m] = (X^a * acc_j - acc_j)[lane + 64 m] + offset, m = 0..15      (J/bootstrap.jl:21 + J/tgsw.jl:125-137)
+THFHE_FN void load_rotated16(int lane, const int32_t *acc_poly, int a2n, uint32_t offset, uint32_t (&t)[16]) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) t[m] = rot_minus_self32(acc_poly, lane + 64 * m, a2n, 1024) + offset;
+}
+// folded complex input of the level-p digit polynomial (p = 1..l)
+THFHE_FN void digits_to_z(const uint32_t (&t)[16], int p, int Bgbit, cplx (&z)[8]) {
+    const int shift = 32 - p * Bgbit;
+    const uint32_t mask = (1u << Bgbit) - 1u;
+    const int32_t half = 1 << (Bgbit - 1);
+#pragma unroll
+    for (int m = 0; m < 8; m++) z[m] = cplx{digit32(t[m], shift, mask, half), digit32(t[m + 8], shift, mask, half)};
+}
+// S[m] += z[m] * B[m*64 + lane]
+THFHE_FN void mac8(int lane, cplx (&S)[8], const cplx (&z)[8], const cplx *B) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        cplx b = B[m * 64 + lane];
+        S[m].re += z[m].re * b.re - z[m].im * b.im;
+        S[m].im += z[m].re * b.im + z[m].im * b.re;
+    }
+}
+// acc_poly[q] += round(lo) + (round(hi) << 16)  for the 16 coefficients this lane owns
+THFHE_FN void acc_update16(int lane, int32_t *acc_poly, const cplx (&zlo)[8], const cplx (&zhi)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        int q = lane + 64 * m;
+        uint32_t vr = round_lo32(zlo[m].re) + (round_lo32(zhi[m].re) << 16);
+        uint32_t vi = round_lo32(zlo[m].im) + (round_lo32(zhi[m].im) << 16);
+        acc_poly[q] = (int32_t)((uint32_t)acc_poly[q] + vr);
+        acc_poly[q + 512] = (int32_t)((uint32_t)acc_poly[q + 512] + vi);
+    }
+}
+// initial accumulator: acc = (0, X^{-barb} * (mu, ..., mu))            (J/bootstrap.jl:60-62,84)
+THFHE_FN void acc_init16(int lane, int32_t *acc_mask, int32_t *acc_body, int barb, int32_t mu) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        int q = lane + 64 * m;
+        int e = (q + barb) & 2047;
+        acc_mask[q] = 0;
+        acc_body[q] = (e & 1024) ? (int32_t)(0u - (uint32_t)mu) : mu;
+    }
+}
+// sample extraction into an LWE(N) record: a'_0 = a_0, a'_j = -a_{N-j}, b = body_0   (J/rlwe.jl:64-68)
+THFHE_FN void extract16(int lane, const int32_t *acc_mask, const int32_t *acc_body, int32_t *out) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        int q = lane + 64 * m;
+        out[q] = q == 0 ? acc_mask[0] : (int32_t)(0u - (uint32_t)acc_mask[1024 - q]);
+    }
+    if (lane == 0) out[1024] = acc_body[0];
+}
+// folded limb inputs of a key polynomial for the key transform
+THFHE_FN void key_limbs_to_z(int lane, const int32_t *poly, cplx (&zlo)[8], cplx (&zhi)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        double l0, h0, l1, h1;
+        split_limbs32(poly[lane + 64 * m], l0, h0);
+        split_limbs32(poly[lane + 64 * m + 512], l1, h1);
+        zlo[m] = cplx{l0, l1};
+        zhi[m] = cplx{h0, h1};
+    }
+}
+
+}  // namespace thfhe
+
+// ---- host-side twiddle table (double precision from long double; identical bytes on device) ---------
+#include <cmath>
+namespace thfhe {
+// T1[k0*64 + lane] = exp(i pi lane (4 k0 + 1) / 1024), T2[k1*8 + j0] = exp(2 pi i j0 k1 / 64)
+inline void make_twiddles_1024(cplx *T1 /*512*/, cplx *T2 /*64*/) {
+    const long double PI = 3.14159265358979323846264338327950288L;
+    for (int k0 = 0; k0 < 8; k0++)
+        for (int lane = 0; lane < 64; lane++) {
+            long double ang = PI * (long double)(lane * (4 * k0 + 1)) / 1024.0L;
+            T1[k0 * 64 + lane] = cplx{(double)cosl(ang), (double)sinl(ang)};
+        }
+    for (int k1 = 0; k1 < 8; k1++)
+        for (int j0 = 0; j0 < 8; j0++) {
+            long double ang = 2.0L * PI * (long double)(j0 * k1) / 64.0L;
+            T2[k1 * 8 + j0] = cplx{(double)cosl(ang), (double)sinl(ang)};
+        }
+}
+}  // namespace thfhe
+
+#endif  // THFHE_LANE_H

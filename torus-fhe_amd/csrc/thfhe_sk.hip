@@ -1,0 +1,632 @@
+// thfhe_sk.hip -- single-key (Torus32) gate bootstrapping on gfx950: kernels + C ABI.
+//
+// Kernels (one HIP stream per context, no host sync inside a call):
+//   sk_key_transform_kernel   BootstrapKey forward_transform step (J/bootstrap.jl:11-12): coefficient-domain TGSW
+//                             rows -> two-limb FP64 spectra in the blind-rotate kernel's register order
+//   sk_prologue_kernel        gate linear part (J/gates.jl:15-177) + mod-switch decode_message(.,2N)
+//                             (J/bootstrap.jl:80-81) -> bara[job][n], barb[job]
+//   sk_blind_rotate_kernel    blind_rotate_and_extract (J/bootstrap.jl:38-65): one wavefront per job, accumulator in
+//                             LDS for all n CMuxes, key spectra streamed with 16-B/lane coalesced loads
+//   sk_keyswitch_kernel       keyswitch (J/keyswitch.jl:45-80) (+ the MUX combine of J/gates.jl:172-176)
+//   sk_linear_kernel          NOT / COPY (J/gates.jl:76-79)
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/thfhe_hip.h"
+#include "thfhe_common.h"
+#include "thfhe_lane.h"
+
+using namespace thfhe;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// key transform
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sk_key_transform_kernel(const int32_t *__restrict__ polys, long npolys,
+                                                                const cplx *__restrict__ tw, cplx *__restrict__ spec) {
+    __shared__ cplx sT1[512];
+    __shared__ cplx sT2[64];
+    __shared__ cplx sX[4][kXbufSlots];
+    for (int t = threadIdx.x; t < 512; t += 256) sT1[t] = tw[t];
+    if (threadIdx.x < 64) sT2[threadIdx.x] = tw[512 + threadIdx.x];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * 4 + wave;
+    if (q >= npolys) return;
+    cplx zlo[8], zhi[8];
+    key_limbs_to_z(lane, polys + q * 1024, zlo, zhi);
+    cplx *xb = sX[wave];
+    wave_fft_fwd(lane, zlo, xb, sT1, sT2);
+    wave_fft_fwd(lane, zhi, xb, sT1, sT2);
+    cplx *out = spec + q * 1024;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        out[m * 64 + lane] = cplx{zlo[m].re * (1.0 / 512), zlo[m].im * (1.0 / 512)};
+        out[512 + m * 64 + lane] = cplx{zhi[m].re * (1.0 / 512), zhi[m].im * (1.0 / 512)};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// prologue: tmp = (0, cb) + cx * x + cy * y ; bara = decode_message(tmp.a, 2N) ; barb likewise
+// ------------------------------------------------------------------------------------------------------
+struct Lin {
+    int32_t cb, cx, cy;
+    int ysel;  // 1: second operand is in1, 2: in2
+};
+__host__ __device__ inline bool gate_lin(int op, int which, Lin &L) {
+    const int32_t E8 = 1 << 29, E4 = 1 << 30;  // encode_message(1,8), (1,4)   J/numeric-functions.jl:86-89
+    switch (op) {
+    case THFHE_NAND: L = Lin{E8, -1, -1, 1}; return true;
+    case THFHE_OR: L = Lin{E8, 1, 1, 1}; return true;
+    case THFHE_AND: L = Lin{-E8, 1, 1, 1}; return true;
+    case THFHE_XOR: L = Lin{E4, 2, 2, 1}; return true;
+    case THFHE_XNOR: L = Lin{-E4, -2, -2, 1}; return true;
+    case THFHE_NOR: L = Lin{-E8, -1, -1, 1}; return true;
+    case THFHE_ANDNY: L = Lin{-E8, -1, 1, 1}; return true;
+    case THFHE_ANDYN: L = Lin{-E8, 1, -1, 1}; return true;
+    case THFHE_ORNY: L = Lin{E8, -1, 1, 1}; return true;
+    case THFHE_ORYN: L = Lin{E8, 1, -1, 1}; return true;
+    case THFHE_MUX: L = which == 0 ? Lin{-E8, 1, 1, 1} : Lin{-E8, -1, 1, 2}; return true;  // J/gates.jl:166-171
+    case kOpIdentity: L = Lin{0, 1, 0, 1}; return true;                                      // plain bootstrap(x)
+    default: return false;
+    }
+}
+
+__global__ __launch_bounds__(256) void sk_prologue_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ in1,
+                                                           const int32_t *__restrict__ in2, int op, int rot_per_gate, int n,
+                                                           int n_pad, int log2_2n, long jobs, int32_t *__restrict__ bara,
+                                                           int32_t *__restrict__ barb) {
+    const long job = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (job >= jobs || i > n) return;
+    const long gate = job / rot_per_gate;
+    const int which = (int)(job % rot_per_gate);
+    Lin L;
+    gate_lin(op, which, L);
+    const size_t off = (size_t)gate * (n + 1) + i;
+    uint32_t v = (uint32_t)L.cx * (uint32_t)in0[off];
+    if (L.cy != 0) v += (uint32_t)L.cy * (uint32_t)(L.ysel == 2 ? in2[off] : in1[off]);
+    if (i == n) {
+        v += (uint32_t)L.cb;
+        barb[job] = modswitch2n((int32_t)v, log2_2n);
+    } else {
+        bara[job * n_pad + i] = modswitch2n((int32_t)v, log2_2n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// blind rotate + extract.  4 waves per workgroup, each wave one job; 78 848 B LDS -> 2 workgroups per CU.
+// ------------------------------------------------------------------------------------------------------
+struct BRArgs {
+    const cplx *bk;        // spectral key
+    const cplx *tw;        // T1[512] ++ T2[64]
+    const int32_t *bara;   // [jobs][n_pad]
+    const int32_t *barb;   // [jobs]
+    int32_t *out;          // [jobs][N+1]
+    long jobs;
+    int n, n_pad, Bgbit;
+    int32_t mu;
+};
+
+template <int L>
+__global__ __launch_bounds__(256, 2) void sk_blind_rotate_kernel(BRArgs a) {
+    __shared__ cplx sT1[512];
+    __shared__ cplx sT2[64];
+    __shared__ int32_t sAcc[4][2048];
+    __shared__ cplx sX[4][kXbufSlots];
+    for (int t = threadIdx.x; t < 512; t += 256) sT1[t] = a.tw[t];
+    if (threadIdx.x < 64) sT2[threadIdx.x] = a.tw[512 + threadIdx.x];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const long job = (long)blockIdx.x * 4 + wave;
+    if (job >= a.jobs) return;
+    int32_t *acc = sAcc[wave];
+    cplx *xb = sX[wave];
+    const int32_t *bara = a.bara + job * a.n_pad;
+    const int Bgbit = a.Bgbit;
+    const uint32_t offset = decomp_offset32(L, Bgbit);
+
+    acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
+    wave_sync();
+
+    for (int i = 0; i < a.n; i++) {
+        const int ai = bara[i];  // wave-uniform
+        if (ai == 0) continue;   // J/bootstrap.jl:40
+        const int a2n = ai & 2047;
+        cplx S[2][2][8];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
+
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            uint32_t t[16];
+            load_rotated16(lane, acc + j * 1024, a2n, offset, t);
+#pragma unroll
+            for (int p = 1; p <= L; p++) {
+                cplx z[8];
+                digits_to_z(t, p, Bgbit, z);
+                wave_fft_fwd(lane, z, xb, sT1, sT2);
+                const cplx *B = a.bk + bk_spec_index(i, j * L + (p - 1), 0, 0, 2 * L);
+                mac8(lane, S[0][0], z, B);
+                mac8(lane, S[0][1], z, B + 512);
+                mac8(lane, S[1][0], z, B + 1024);
+                mac8(lane, S[1][1], z, B + 1536);
+            }
+        }
+        wave_sync();  // every rotated read of acc precedes the updates below
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            wave_fft_inv(lane, S[c][0], xb, sT1, sT2);
+            wave_fft_inv(lane, S[c][1], xb, sT1, sT2);
+            acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
+        }
+        wave_sync();
+    }
+    extract16(lane, acc, acc + 1024, a.out + job * 1025);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// key switch.  One workgroup (4 waves) per gate; wave w takes input coordinates i = w (mod 4); every lane keeps
+// its 4*NX4 + 2*NX2 words of the padded output row in registers.  KSK rows are padded to 64*(4*NX4+2*NX2) words
+// (n = 630: 640 words = 2560 B, 16-B aligned): per row each lane issues NX4 16-byte and NX2 8-byte loads.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sk_ksk_pad_kernel(const int32_t *__restrict__ src, long rows, int n, int row_words,
+                                                          int32_t *__restrict__ dst) {
+    const long r = blockIdx.x;
+    if (r >= rows) return;
+    for (int q = threadIdx.x; q < row_words; q += 256) dst[r * row_words + q] = q <= n ? src[r * (n + 1) + q] : 0;
+}
+
+struct KSArgs {
+    const int32_t *ksk;  // [N][t][base-1][row_words]
+    const int32_t *u;    // [jobs][N+1]
+    int32_t *out;        // [gates][n+1]
+    long gates;
+    int rot_per_gate;    // 1, or 2 for MUX: input = (0, 2^29) + u1 + u2     (J/gates.jl:172-176)
+    int n, t, basebit;
+};
+
+template <int NX4, int NX2>
+__global__ __launch_bounds__(256) void sk_keyswitch_kernel(KSArgs a) {
+    constexpr int ROW = 64 * (4 * NX4 + 2 * NX2);
+    __shared__ uint32_t sA[1024];
+    __shared__ uint32_t sRed[3][ROW];
+    const long g = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t prec_offset = 1u << (32 - (1 + a.basebit * a.t));
+    const int32_t *u1 = a.u + (size_t)g * a.rot_per_gate * 1025;
+    for (int q = tid; q < 1024; q += 256) {
+        uint32_t v = (uint32_t)u1[q];
+        if (a.rot_per_gate == 2) v += (uint32_t)u1[1025 + q];
+        sA[q] = v + prec_offset;
+    }
+    __syncthreads();
+    const int base1 = (1 << a.basebit) - 1;
+    const uint32_t mask = (uint32_t)base1;
+    uint32_t r4[NX4 > 0 ? NX4 : 1][4];
+    uint32_t r2[NX2 > 0 ? NX2 : 1][2];
+#pragma unroll
+    for (int c = 0; c < NX4; c++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) r4[c][q] = 0;
+    r2[0][0] = r2[0][1] = 0;
+    for (int i = wave; i < 1024; i += 4) {
+        const uint32_t ai = sA[i];
+        const int32_t *rowi = a.ksk + (size_t)i * a.t * base1 * ROW;
+        for (int j = 0; j < a.t; j++) {
+            const uint32_t d = (ai >> (32 - (j + 1) * a.basebit)) & mask;
+            if (d == 0) continue;  // wave-uniform
+            const int32_t *row = rowi + ((size_t)j * base1 + (d - 1)) * ROW;
+#pragma unroll
+            for (int c = 0; c < NX4; c++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(row + c * 256 + 4 * lane);
+                r4[c][0] -= x.x; r4[c][1] -= x.y; r4[c][2] -= x.z; r4[c][3] -= x.w;
+            }
+            if (NX2 > 0) {
+                const uint2 x = *reinterpret_cast<const uint2 *>(row + NX4 * 256 + 2 * lane);
+                r2[0][0] -= x.x; r2[0][1] -= x.y;
+            }
+        }
+    }
+    if (wave > 0) {
+        uint32_t *red = sRed[wave - 1];
+#pragma unroll
+        for (int c = 0; c < NX4; c++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) red[c * 256 + 4 * lane + q] = r4[c][q];
+        if (NX2 > 0) {
+            red[NX4 * 256 + 2 * lane] = r2[0][0];
+            red[NX4 * 256 + 2 * lane + 1] = r2[0][1];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t b = (uint32_t)u1[1024];
+        if (a.rot_per_gate == 2) b += (uint32_t)u1[1025 + 1024] + (1u << 29);
+        int32_t *out = a.out + (size_t)g * (a.n + 1);
+        auto emit = [&](int q, uint32_t v) {
+            v += sRed[0][q] + sRed[1][q] + sRed[2][q];
+            if (q == a.n) v += b;
+            if (q <= a.n) out[q] = (int32_t)v;
+        };
+#pragma unroll
+        for (int c = 0; c < NX4; c++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) emit(c * 256 + 4 * lane + q, r4[c][q]);
+        if (NX2 > 0) {
+            emit(NX4 * 256 + 2 * lane, r2[0][0]);
+            emit(NX4 * 256 + 2 * lane + 1, r2[0][1]);
+        }
+    }
+}
+
+// words per lane of a padded KSK row: smallest even W with 64*W >= n+1
+inline int ks_words_per_lane(int n) { return (((n + 1 + 63) / 64) + 1) & ~1; }
+
+__global__ __launch_bounds__(256) void sk_linear_kernel(const int32_t *__restrict__ in0, int32_t *__restrict__ out, size_t words, int negate) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < words) out[q] = negate ? (int32_t)(0u - (uint32_t)in0[q]) : in0[q];
+}
+
+}  // namespace
+
+// ======================================================================================================
+// host side
+// ======================================================================================================
+struct thfhe_ctx {
+    thfhe_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    cplx *d_bk = nullptr;     // spectral key
+    int32_t *d_ksk = nullptr; // padded rows
+    int ks_w = 0;             // words per lane of a padded KSK row
+    cplx *d_tw = nullptr;
+    // workspace
+    size_t cap_jobs = 0;
+    int n_pad = 0;
+    int32_t *d_bara = nullptr, *d_barb = nullptr, *d_u = nullptr;
+    // staging for the host-buffer API
+    size_t cap_stage = 0;
+    int32_t *d_in[3] = {nullptr, nullptr, nullptr};
+    int32_t *d_out = nullptr;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    std::mutex mu;
+};
+
+namespace {
+
+int ensure_workspace(thfhe_ctx *c, size_t jobs) {
+    if (jobs <= c->cap_jobs) return THFHE_OK;
+    (void)hipFree(c->d_bara);
+    (void)hipFree(c->d_barb);
+    (void)hipFree(c->d_u);
+    c->d_bara = c->d_barb = c->d_u = nullptr;
+    c->cap_jobs = 0;
+    THFHE_HIP(hipMalloc(&c->d_bara, jobs * c->n_pad * sizeof(int32_t)));
+    THFHE_HIP(hipMalloc(&c->d_barb, jobs * sizeof(int32_t)));
+    THFHE_HIP(hipMalloc(&c->d_u, jobs * 1025 * sizeof(int32_t)));
+    c->cap_jobs = jobs;
+    return THFHE_OK;
+}
+
+int ensure_stage(thfhe_ctx *c, size_t words) {
+    if (words <= c->cap_stage) return THFHE_OK;
+    for (auto &p : c->d_in) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    (void)hipFree(c->d_out);
+    c->d_out = nullptr;
+    c->cap_stage = 0;
+    for (auto &p : c->d_in) THFHE_HIP(hipMalloc(&p, words * sizeof(int32_t)));
+    THFHE_HIP(hipMalloc(&c->d_out, words * sizeof(int32_t)));
+    c->cap_stage = words;
+    return THFHE_OK;
+}
+
+template <int L>
+void launch_br(const BRArgs &a, hipStream_t s) {
+    const unsigned blocks = (unsigned)((a.jobs + 3) / 4);
+    hipLaunchKernelGGL(sk_blind_rotate_kernel<L>, dim3(blocks), dim3(256), 0, s, a);
+}
+
+// rotations (prologue + blind rotate) of `jobs` = gates * rot_per_gate jobs into c->d_u
+int enqueue_rotations(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1, const int32_t *d2, size_t gates,
+                      int rot_per_gate, int32_t mu) {
+    const size_t jobs = gates * rot_per_gate;
+    int rc = ensure_workspace(c, jobs);
+    if (rc) return rc;
+    const int n = c->p.n;
+    if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[0], c->stream));
+    dim3 pg((unsigned)((n + 1 + 255) / 256), (unsigned)jobs);
+    hipLaunchKernelGGL(sk_prologue_kernel, pg, dim3(256), 0, c->stream, d0, d1, d2, op, rot_per_gate, n, c->n_pad,
+                       ilog2(2 * c->p.N), (long)jobs, c->d_bara, c->d_barb);
+    if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[1], c->stream));
+    BRArgs a{c->d_bk, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)jobs, n, c->n_pad, c->p.Bgbit, mu};
+    switch (c->p.l) {
+    case 1: launch_br<1>(a, c->stream); break;
+    case 2: launch_br<2>(a, c->stream); break;
+    case 3: launch_br<3>(a, c->stream); break;
+    case 4: launch_br<4>(a, c->stream); break;
+    default: return thfhe_fail(THFHE_E_UNSUPPORTED, "decomposition length l must be 1..4");
+    }
+    if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[2], c->stream));
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+
+int enqueue_keyswitch(thfhe_ctx *c, const int32_t *d_u, int32_t *d_out, size_t gates, int rot_per_gate, bool timed) {
+    KSArgs k{c->d_ksk, d_u, d_out, (long)gates, rot_per_gate, c->p.n, c->p.ks_t, c->p.ks_basebit};
+    const dim3 grid((unsigned)gates), block(256);
+    switch (c->ks_w) {
+#define THFHE_KS_CASE(W, X4, X2) \
+    case W: hipLaunchKernelGGL((sk_keyswitch_kernel<X4, X2>), grid, block, 0, c->stream, k); break;
+        THFHE_KS_CASE(2, 0, 1) THFHE_KS_CASE(4, 1, 0) THFHE_KS_CASE(6, 1, 1) THFHE_KS_CASE(8, 2, 0) THFHE_KS_CASE(10, 2, 1)
+        THFHE_KS_CASE(12, 3, 0) THFHE_KS_CASE(14, 3, 1) THFHE_KS_CASE(16, 4, 0) THFHE_KS_CASE(18, 4, 1) THFHE_KS_CASE(20, 5, 0)
+        THFHE_KS_CASE(22, 5, 1)
+#undef THFHE_KS_CASE
+    default: return thfhe_fail(THFHE_E_UNSUPPORTED, "LWE dimension n too large for the key-switch kernel (n <= 1407)");
+    }
+    if (timed && c->profiling) {
+        THFHE_HIP(hipEventRecord(c->ev[3], c->stream));
+        c->ev_valid = true;
+    }
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+
+int gates_dev_locked(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1, const int32_t *d2, int32_t *dout, size_t count) {
+    if (count == 0) return THFHE_OK;
+    if (count > (size_t)INT32_MAX / 4) return thfhe_fail(THFHE_E_INVALID, "count too large");
+    THFHE_HIP(hipSetDevice(c->device));
+    if (op == THFHE_NOT || op == THFHE_COPY) {
+        const size_t words = count * (c->p.n + 1);
+        hipLaunchKernelGGL(sk_linear_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->stream, d0, dout, words,
+                           op == THFHE_NOT ? 1 : 0);
+        THFHE_HIP(hipGetLastError());
+        return THFHE_OK;
+    }
+    Lin L;
+    if (!gate_lin(op, 0, L) || op == kOpIdentity) return thfhe_fail(THFHE_E_INVALID, "unknown gate opcode");
+    if (!d0 || !d1 || (op == THFHE_MUX && !d2)) return thfhe_fail(THFHE_E_INVALID, "null operand");
+    const int rot = op == THFHE_MUX ? 2 : 1;
+    int rc = enqueue_rotations(c, op, d0, d1, d2, count, rot, 1 << 29);
+    if (rc) return rc;
+    return enqueue_keyswitch(c, c->d_u, dout, count, rot, true);
+}
+
+}  // namespace
+
+extern "C" {
+
+int thfhe_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int thfhe_ctx_create(const thfhe_params *p, const int32_t *bk_coeff, const int32_t *ksk, int device, thfhe_ctx **out) {
+    if (!p || !bk_coeff || !ksk || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    *out = nullptr;
+    if (p->torus_bits != 32 || p->parties != 1) return thfhe_fail(THFHE_E_UNSUPPORTED, "thfhe_ctx_create is the single-key Torus32 path; use thfhe_mk_ctx_create");
+    if (p->N != 1024 || p->k != 1) return thfhe_fail(THFHE_E_UNSUPPORTED, "only N = 1024, k = 1 is implemented");
+    if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || p->Bgbit > 10 || p->l * p->Bgbit > 32)
+        return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 4, Bgbit <= 10 (FP64 exactness bound), l*Bgbit <= 32");
+    if (p->n < 1 || p->n > 1407) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= n <= 1407");
+    if (p->ks_t < 1 || p->ks_basebit < 1 || p->ks_t * p->ks_basebit > 31) return thfhe_fail(THFHE_E_INVALID, "bad key-switch parameters");
+    if (thfhe_device_count() <= device || device < 0) return thfhe_fail(THFHE_E_NO_DEVICE, "no usable HIP device (this library has no CPU fallback)");
+    THFHE_HIP(hipSetDevice(device));
+    thfhe_ctx *c = new (std::nothrow) thfhe_ctx;
+    if (!c) return thfhe_fail(THFHE_E_NOMEM, "out of host memory");
+    c->p = *p;
+    c->device = device;
+    c->n_pad = (p->n + 3) & ~3;
+    c->ks_w = ks_words_per_lane(p->n);
+    const int row_words = 64 * c->ks_w;
+    int rc = THFHE_OK;
+    auto fail = [&](int code) {
+        thfhe_ctx_destroy(c);
+        return code;
+    };
+#define CK(expr)                                                   \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) return fail(thfhe_fail_hip(e_, #expr)); \
+    } while (0)
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &e : c->ev) CK(hipEventCreate(&e));
+    // twiddles
+    std::vector<cplx> tw(576);
+    make_twiddles_1024(tw.data(), tw.data() + 512);
+    CK(hipMalloc(&c->d_tw, tw.size() * sizeof(cplx)));
+    CK(hipMemcpyAsync(c->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
+    // bootstrapping key: upload coefficients, transform on device
+    const long npolys = (long)p->n * 2 * p->l * 2;
+    int32_t *d_coeff = nullptr;
+    CK(hipMalloc(&d_coeff, (size_t)npolys * 1024 * sizeof(int32_t)));
+    CK(hipMemcpyAsync(d_coeff, bk_coeff, (size_t)npolys * 1024 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    CK(hipMalloc(&c->d_bk, (size_t)npolys * 1024 * sizeof(cplx)));
+    hipLaunchKernelGGL(sk_key_transform_kernel, dim3((unsigned)((npolys + 3) / 4)), dim3(256), 0, c->stream, d_coeff, npolys, c->d_tw, c->d_bk);
+    CK(hipGetLastError());
+    // key-switching key: pad rows to 640 words
+    const long rows = (long)p->N * p->ks_t * ((1 << p->ks_basebit) - 1);
+    int32_t *d_raw = nullptr;
+    CK(hipMalloc(&d_raw, (size_t)rows * (p->n + 1) * sizeof(int32_t)));
+    CK(hipMemcpyAsync(d_raw, ksk, (size_t)rows * (p->n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    CK(hipMalloc(&c->d_ksk, (size_t)rows * row_words * sizeof(int32_t)));
+    hipLaunchKernelGGL(sk_ksk_pad_kernel, dim3((unsigned)rows), dim3(256), 0, c->stream, d_raw, rows, p->n, row_words, c->d_ksk);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_coeff);
+    (void)hipFree(d_raw);
+#undef CK
+    (void)rc;
+    *out = c;
+    return THFHE_OK;
+}
+
+void thfhe_ctx_destroy(thfhe_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_bk);
+    (void)hipFree(c->d_ksk);
+    (void)hipFree(c->d_tw);
+    (void)hipFree(c->d_bara);
+    (void)hipFree(c->d_barb);
+    (void)hipFree(c->d_u);
+    for (auto &p : c->d_in) hipFree(p);
+    (void)hipFree(c->d_out);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int thfhe_ctx_params(const thfhe_ctx *c, thfhe_params *out) {
+    if (!c || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    *out = c->p;
+    return THFHE_OK;
+}
+
+void *thfhe_dev_alloc(thfhe_ctx *c, size_t bytes) {
+    if (!c) return nullptr;
+    void *p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+void thfhe_dev_free(thfhe_ctx *c, void *p) {
+    if (c) (void)hipSetDevice(c->device);
+    (void)hipFree(p);
+}
+int thfhe_copy_h2d(thfhe_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    THFHE_HIP(hipSetDevice(c->device));
+    THFHE_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+int thfhe_copy_d2h(thfhe_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    THFHE_HIP(hipSetDevice(c->device));
+    THFHE_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+int thfhe_reserve(thfhe_ctx *c, size_t max_count) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    return ensure_workspace(c, max_count * 2);
+}
+int thfhe_sync(thfhe_ctx *c) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+int thfhe_set_profiling(thfhe_ctx *c, int enabled) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    c->profiling = enabled != 0;
+    c->ev_valid = false;
+    return THFHE_OK;
+}
+int thfhe_last_timings(thfhe_ctx *c, float ms[4]) {
+    if (!c || !ms) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (!c->ev_valid) return thfhe_fail(THFHE_E_INVALID, "no profiled call recorded");
+    THFHE_HIP(hipEventSynchronize(c->ev[3]));
+    THFHE_HIP(hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));
+    THFHE_HIP(hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));
+    THFHE_HIP(hipEventElapsedTime(&ms[2], c->ev[2], c->ev[3]));
+    THFHE_HIP(hipEventElapsedTime(&ms[3], c->ev[0], c->ev[3]));
+    return THFHE_OK;
+}
+
+int thfhe_gates_dev(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1, const int32_t *d2, int32_t *dout, size_t count) {
+    if (!c || !d0 || !dout) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    return gates_dev_locked(c, op, d0, d1, d2, dout, count);
+}
+
+int thfhe_gates(thfhe_ctx *c, int op, const int32_t *in0, const int32_t *in1, const int32_t *in2, int32_t *out, size_t count) {
+    if (!c || !in0 || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t words = count * (c->p.n + 1), bytes = words * sizeof(int32_t);
+    int rc = ensure_stage(c, words);
+    if (rc) return rc;
+    const int32_t *src[3] = {in0, in1, in2};
+    for (int q = 0; q < 3; q++)
+        if (src[q]) THFHE_HIP(hipMemcpyAsync(c->d_in[q], src[q], bytes, hipMemcpyHostToDevice, c->stream));
+    rc = gates_dev_locked(c, op, c->d_in[0], in1 ? c->d_in[1] : nullptr, in2 ? c->d_in[2] : nullptr, c->d_out, count);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));  // after all input copies: aliasing-safe
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+int thfhe_bootstrap_wo_keyswitch(thfhe_ctx *c, int32_t mu, const int32_t *x, int32_t *out_N1, size_t count) {
+    if (!c || !x || !out_N1) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t words = count * (c->p.n + 1);
+    int rc = ensure_stage(c, words);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(c->d_in[0], x, words * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    rc = enqueue_rotations(c, kOpIdentity, c->d_in[0], c->d_in[0], nullptr, count, 1, mu);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(out_N1, c->d_u, count * 1025 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+int thfhe_bootstrap(thfhe_ctx *c, int32_t mu, const int32_t *x, int32_t *out, size_t count) {
+    if (!c || !x || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t words = count * (c->p.n + 1);
+    int rc = ensure_stage(c, words);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(c->d_in[0], x, words * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    rc = enqueue_rotations(c, kOpIdentity, c->d_in[0], c->d_in[0], nullptr, count, 1, mu);
+    if (rc) return rc;
+    rc = enqueue_keyswitch(c, c->d_u, c->d_out, count, 1, false);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(out, c->d_out, words * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+int thfhe_keyswitch(thfhe_ctx *c, const int32_t *in_N1, int32_t *out, size_t count) {
+    if (!c || !in_N1 || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    int rc = ensure_workspace(c, count);
+    if (rc) return rc;
+    rc = ensure_stage(c, count * (c->p.n + 1));
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(c->d_u, in_N1, count * 1025 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    rc = enqueue_keyswitch(c, c->d_u, c->d_out, count, 1, false);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(out, c->d_out, count * (c->p.n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+"""thfhe -- Python host layer over the C ABI of libthfhe_hip.so (include/thfhe_hip.h).
+
+Mirrors the reference's gate/bootstrapping interface for the hot path (3-gen-mk-tfhe/src/gates.jl,
+bootstrap.jl, keyswitch.jl, 3gen_mk_gates.jl, 3gen_mk_internals.jl): same function names, argument
+order and meaning, with numpy int32 LWE records ([..., n+1] = a..., b) instead of Julia structs.
+There is no CPU fallback: importing works anywhere (so the ABI can be inspected), but creating a
+context or evaluating a gate without a usable HIP device raises ThfheError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libthfhe_hip.so")
+
+# gate opcodes (include/thfhe_hip.h enum thfhe_gate)
+NAND, OR, AND, XOR, XNOR, NOR, ANDNY, ANDYN, ORNY, ORYN, MUX, NOT, COPY, AND3 = range(14)
+
+MU8 = 1 << 29     # encode_message(1, 8), Torus32      (numeric-functions.jl:86-89)
+MU8_64 = 1 << 61  # encode_message64(1, 8), Torus64    (numeric-functions.jl:92-95)
+
+
+class ThfheError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """thfhe_params (include/thfhe_hip.h)."""
+    _fields_ = [(f, C.c_int32) for f in
+                ("n", "N", "k", "l", "Bgbit", "ks_t", "ks_basebit", "torus_bits", "parties")]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+# the reference's parameter tables for this path (api.jl:76-115, src/libthfhe.cpp:316-338, mk_api.jl:32-146)
+PARAM_SETS = {
+    "SK-80": dict(n=500, N=1024, k=1, l=2, Bgbit=10, ks_t=8, ks_basebit=2, torus_bits=32, parties=1),
+    "SK-128": dict(n=630, N=1024, k=1, l=3, Bgbit=7, ks_t=8, ks_basebit=2, torus_bits=32, parties=1),
+    "SK-lib": dict(n=1024, N=1024, k=1, l=3, Bgbit=7, ks_t=8, ks_basebit=2, torus_bits=32, parties=1),
+    "MK2": dict(n=520, N=1024, k=1, l=2, Bgbit=7, ks_t=3, ks_basebit=3, torus_bits=64, parties=2),
+    "MK3": dict(n=510, N=1024, k=1, l=2, Bgbit=7, ks_t=5, ks_basebit=2, torus_bits=64, parties=3),
+    "MK4": dict(n=510, N=1024, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
+}
+
+
+def make_params(name=None, **kw):
+    d = dict(PARAM_SETS[name]) if name else {}
+    d.update(kw)
+    return Params(**d)
+
+
+_lib = None
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# symbol -> (restype, argtypes); tests/test_abi.py checks every symbol declared in include/*.h is exported
+SIGNATURES = {
+    "thfhe_last_error": (C.c_char_p, []),
+    "thfhe_device_count": (C.c_int, []),
+    "thfhe_ctx_create": (C.c_int, [C.POINTER(Params), _i32p, _i32p, C.c_int, C.POINTER(_vp)]),
+    "thfhe_ctx_destroy": (None, [_vp]),
+    "thfhe_ctx_params": (C.c_int, [_vp, C.POINTER(Params)]),
+    "thfhe_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
+    "thfhe_bootstrap": (C.c_int, [_vp, C.c_int32, _i32p, _i32p, C.c_size_t]),
+    "thfhe_bootstrap_wo_keyswitch": (C.c_int, [_vp, C.c_int32, _i32p, _i32p, C.c_size_t]),
+    "thfhe_keyswitch": (C.c_int, [_vp, _i32p, _i32p, C.c_size_t]),
+    "thfhe_dev_alloc": (_vp, [_vp, C.c_size_t]),
+    "thfhe_dev_free": (None, [_vp, _vp]),
+    "thfhe_copy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "thfhe_copy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "thfhe_reserve": (C.c_int, [_vp, C.c_size_t]),
+    "thfhe_gates_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "thfhe_sync": (C.c_int, [_vp]),
+    "thfhe_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "thfhe_last_timings": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "thfhe_mk_ctx_create": (C.c_int, [C.POINTER(Params), _i64p, _i32p, C.c_int, C.POINTER(_vp)]),
+    "thfhe_mk_ctx_destroy": (None, [_vp]),
+    "thfhe_mk_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
+    "thfhe_mk_bootstrap": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, C.c_size_t]),
+    "thfhe_mk_dev_alloc": (_vp, [_vp, C.c_size_t]),
+    "thfhe_mk_dev_free": (None, [_vp, _vp]),
+    "thfhe_mk_copy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "thfhe_mk_copy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "thfhe_mk_reserve": (C.c_int, [_vp, C.c_size_t]),
+    "thfhe_mk_gates_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "thfhe_mk_sync": (C.c_int, [_vp]),
+    "thfhe_mk_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "thfhe_mk_last_timings": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+}
+
+
+def lib():
+    """Load libthfhe_hip.so (built in-tree by __graft_entry__.build()); fail loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ThfheError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise ThfheError(f"libthfhe_hip error {rc}: {lib().thfhe_last_error().decode()}")
+
+
+def _p32(a):
+    return a.ctypes.data_as(_i32p) if a is not None else None
+
+
+def _rec(a, words):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if a.shape[-1] != words:
+        raise ValueError(f"expected records of {words} int32 words, got shape {a.shape}")
+    return a.reshape(-1, words)
+
+
+class DeviceBuffer:
+    """A device allocation owned by a context (records resident in HBM)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        self.ptr = ctx._alloc(nbytes)
+        if not self.ptr:
+            raise ThfheError("device allocation failed")
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._h2d(self.ptr, arr)
+        return self
+
+    def download(self, shape, dtype=np.int32):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._d2h(out, self.ptr)
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx._free(self.ptr)
+            self.ptr = None
+
+
+class CloudKey:
+    """Single-key evaluation context = the reference's CloudKey (api.jl:215-231): bootstrap key + keyswitch key,
+    held on one MI355X in the engine's transformed layout.
+
+    bk_coeff: int32[n][(k+1)l][k+1][N] coefficient-domain TGSW rows; ksk: int32[N][t][base-1][n+1].
+    """
+
+    def __init__(self, params, bk_coeff, ksk, device=0):
+        self.params = params
+        bk = np.ascontiguousarray(bk_coeff, np.int32)
+        ks = np.ascontiguousarray(ksk, np.int32)
+        p = params
+        if bk.size != p.n * (p.k + 1) * p.l * (p.k + 1) * p.N:
+            raise ValueError("bk_coeff has the wrong size for these parameters")
+        if ks.size != p.N * p.k * p.ks_t * ((1 << p.ks_basebit) - 1) * (p.n + 1):
+            raise ValueError("ksk has the wrong size for these parameters")
+        h = _vp()
+        _check(lib().thfhe_ctx_create(C.byref(p), _p32(bk), _p32(ks), device, C.byref(h)))
+        self.h = h
+        self.words = p.n + 1
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().thfhe_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # -- host-buffer calls -------------------------------------------------------------------------
+    def gates(self, op, x, y=None, z=None):
+        x = _rec(x, self.words)
+        y = _rec(y, self.words) if y is not None else None
+        z = _rec(z, self.words) if z is not None else None
+        out = np.empty_like(x)
+        _check(lib().thfhe_gates(self.h, op, _p32(x), _p32(y), _p32(z), _p32(out), x.shape[0]))
+        return out
+
+    def bootstrap(self, x, mu=MU8):
+        x = _rec(x, self.words)
+        out = np.empty_like(x)
+        _check(lib().thfhe_bootstrap(self.h, mu, _p32(x), _p32(out), x.shape[0]))
+        return out
+
+    def bootstrap_wo_keyswitch(self, x, mu=MU8):
+        x = _rec(x, self.words)
+        out = np.empty((x.shape[0], self.params.N + 1), np.int32)
+        _check(lib().thfhe_bootstrap_wo_keyswitch(self.h, mu, _p32(x), _p32(out), x.shape[0]))
+        return out
+
+    def keyswitch(self, u):
+        u = _rec(u, self.params.N + 1)
+        out = np.empty((u.shape[0], self.words), np.int32)
+        _check(lib().thfhe_keyswitch(self.h, _p32(u), _p32(out), u.shape[0]))
+        return out
+
+    # -- device-buffer calls -----------------------------------------------------------------------
+    def _alloc(self, n):
+        return lib().thfhe_dev_alloc(self.h, n)
+
+    def _free(self, p):
+        lib().thfhe_dev_free(self.h, p)
+
+    def _h2d(self, dptr, arr):
+        _check(lib().thfhe_copy_h2d(self.h, dptr, arr.ctypes.data_as(_vp), arr.nbytes))
+
+    def _d2h(self, arr, dptr):
+        _check(lib().thfhe_copy_d2h(self.h, arr.ctypes.data_as(_vp), dptr, arr.nbytes))
+
+    def device_records(self, count):
+        return DeviceBuffer(self, count * self.words * 4)
+
+    def reserve(self, max_count):
+        _check(lib().thfhe_reserve(self.h, max_count))
+
+    def gates_dev(self, op, dx, dy, dz, dout, count):
+        _check(lib().thfhe_gates_dev(self.h, op, dx.ptr, dy.ptr if dy else None, dz.ptr if dz else None, dout.ptr, count))
+
+    def sync(self):
+        _check(lib().thfhe_sync(self.h))
+
+    def set_profiling(self, on):
+        _check(lib().thfhe_set_profiling(self.h, int(bool(on))))
+
+    def last_timings(self):
+        ms = (C.c_float * 4)()
+        _check(lib().thfhe_last_timings(self.h, ms))
+        return dict(prologue_ms=ms[0], blind_rotate_ms=ms[1], keyswitch_ms=ms[2], total_ms=ms[3])
+
+
+# ---- the reference's single-key gate API (gates.jl:15-177), batched over the leading axis -------------
+def gate_nand(ck, x, y): return ck.gates(NAND, x, y)
+def gate_or(ck, x, y): return ck.gates(OR, x, y)
+def gate_and(ck, x, y): return ck.gates(AND, x, y)
+def gate_xor(ck, x, y): return ck.gates(XOR, x, y)
+def gate_xnor(ck, x, y): return ck.gates(XNOR, x, y)
+def gate_nor(ck, x, y): return ck.gates(NOR, x, y)
+def gate_andny(ck, x, y): return ck.gates(ANDNY, x, y)
+def gate_andyn(ck, x, y): return ck.gates(ANDYN, x, y)
+def gate_orny(ck, x, y): return ck.gates(ORNY, x, y)
+def gate_oryn(ck, x, y): return ck.gates(ORYN, x, y)
+def gate_mux(ck, x, y, z): return ck.gates(MUX, x, y, z)
+def gate_not(ck, x): return ck.gates(NOT, x)
+
+
+def gate_constant(ck, value):
+    """gates.jl:91-93: noiseless trivial sample of +-1/8 (not encrypted)."""
+    r = np.zeros(ck.words, np.int32)
+    r[-1] = MU8 if value else -MU8
+    return r
+
+
+def bootstrap(ck, mu, x): return ck.bootstrap(x, mu)                              # bootstrap.jl:98-101
+def bootstrap_wo_keyswitch(ck, mu, x): return ck.bootstrap_wo_keyswitch(x, mu)    # bootstrap.jl:75-88
+def keyswitch(ck, u): return ck.keyswitch(u)                                      # keyswitch.jl:45-80
