@@ -27,23 +27,27 @@ typedef unsigned __int128 u128;
 #define GL_P 0xFFFFFFFF00000001ULL
 #define GL_EPS 0xFFFFFFFFULL /* 2^64 mod p */
 
+/* branch-free: data-dependent branches mispredict half the time on random residues */
 static inline uint64_t gl_add(uint64_t a, uint64_t b) {
     uint64_t s = a + b;
-    if (s < a) s += GL_EPS; /* wrapped: +2^64 == +EPS (a,b < p so no second wrap) */
-    if (s >= GL_P) s -= GL_P;
+    s += (0 - (uint64_t)(s < a)) & GL_EPS; /* wrapped: +2^64 == +EPS (a,b < p so no second wrap) */
+    s -= (0 - (uint64_t)(s >= GL_P)) & GL_P;
     return s;
 }
-static inline uint64_t gl_sub(uint64_t a, uint64_t b) { return (a >= b) ? a - b : a + (GL_P - b); }
+static inline uint64_t gl_sub(uint64_t a, uint64_t b) {
+    uint64_t d = a - b;
+    return d + ((0 - (uint64_t)(a < b)) & GL_P); /* borrow: + p (mod 2^64) */
+}
 static inline uint64_t gl_reduce128(u128 x) {
     uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
     uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
     /* x = lo + hi_lo*2^64 + hi_hi*2^96 == lo + hi_lo*(2^32-1) - hi_hi  (mod p) */
     uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;
+    t0 -= (0 - (uint64_t)(lo < hi_hi)) & GL_EPS;
     uint64_t t1 = hi_lo * GL_EPS;
     uint64_t r = t0 + t1;
-    if (r < t1) r += GL_EPS;
-    if (r >= GL_P) r -= GL_P;
+    r += (0 - (uint64_t)(r < t1)) & GL_EPS;
+    r -= (0 - (uint64_t)(r >= GL_P)) & GL_P;
     return r;
 }
 static inline uint64_t gl_mul(uint64_t a, uint64_t b) { return gl_reduce128((u128)a * b); }
@@ -474,6 +478,7 @@ int oracle_gates(const oracle_ctx *c, int op, const int32_t *in0, const int32_t 
     lin_t L;
     if (gate_lin(op, 0, &L)) return -1;
     int32_t *res = (int32_t *)malloc(sizeof(int32_t) * count * rec); /* tolerate out aliasing an input */
+    /* one thread per gate: the reference's only parallel pattern (src/KNN_medical_data.cpp:681) */
 #pragma omp parallel for schedule(dynamic)
     for (long g = 0; g < (long)count; g++) {
         int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (rec + 2 * ((size_t)Nk + 1)));

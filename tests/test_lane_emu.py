@@ -1,0 +1,106 @@
+"""CPU check of the GPU kernel's lane-level code (torus-fhe_amd/csrc/thfhe_lane.h) replayed on the host by
+tests/emu/lane_emu.cpp: transform correctness, exactness margin of the split-limb FP64 product, CMux and blind
+rotation bit-for-bit against the oracle's schoolbook path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def E():
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emu")], check=True)
+    L = C.CDLL(os.path.join(HERE, "emu", "liblane_emu.so"))
+    L.emu_polymul.restype = C.c_double
+    return L
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def test_forward_transform_matches_definition(E):
+    # P_k = sum_j z_j zeta^(j(4k+1)), zeta = exp(i pi / N); lane (k1 + 8 k0), register k2 holds k = k0 + 8 k1 + 64 k2
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal(512) + 1j * rng.standard_normal(512)
+    zin = np.ascontiguousarray(np.stack([z.real, z.imag], -1)).ravel()
+    out = np.zeros(64 * 8 * 2)
+    E.emu_fwd_raw(dptr(zin), dptr(out))
+    got = out.reshape(64, 8, 2)
+    got = got[..., 0] + 1j * got[..., 1]
+    j = np.arange(512)
+    k = np.arange(512)
+    ang = (np.outer(4 * k + 1, j) % 2048) * (np.pi / 1024)
+    P = (np.exp(1j * ang) * z[None, :]).sum(axis=1)
+    exp = np.zeros((64, 8), complex)
+    for k0 in range(8):
+        for k1 in range(8):
+            for k2 in range(8):
+                exp[k1 + 8 * k0, k2] = P[k0 + 8 * k1 + 64 * k2]
+    assert np.abs(got - exp).max() < 1e-10
+    back = np.zeros(1024)
+    E.emu_inv_raw(dptr(out), dptr(back))
+    zb = back.reshape(512, 2)
+    assert np.abs((zb[:, 0] + 1j * zb[:, 1]) / 512 - z).max() < 1e-13
+
+
+@pytest.mark.parametrize("case", ["random7", "random10", "worst_neg", "worst_alt"])
+def test_polymul_exact_with_margin(E, O, case):
+    # exactness claim of DESIGN.md section 4: every inverse-transform output is within << 1/2 of an integer
+    N = 1024
+    rng = np.random.default_rng(1)
+    if case == "random7":
+        a = rng.integers(-64, 64, N); b = rng.integers(-2**31, 2**31, N)
+    elif case == "random10":
+        a = rng.integers(-512, 512, N); b = rng.integers(-2**31, 2**31, N)
+    elif case == "worst_neg":
+        a = np.full(N, -512); b = np.full(N, -2**31)
+    else:
+        a = 511 * (-1) ** np.arange(N); b = np.full(N, 2**31 - 1)
+    a = a.astype(np.int32); b = b.astype(np.int32)
+    ref, got = np.zeros(N, np.int32), np.zeros(N, np.int32)
+    O.lib().oracle_polymul_schoolbook32(O.p32(a), O.p32(b), N, O.p32(ref))
+    margin = E.emu_polymul(O.p32(a), O.p32(b), O.p32(got))
+    assert np.array_equal(ref, got)
+    assert margin < 1e-3
+
+
+def test_cmux_and_blind_rotate_bit_exact(E, O, sk_small):
+    p, K, orc = sk_small
+    npolys = K.bk.size // 1024
+    spec = np.zeros(npolys * 2 * 512 * 2, np.float64)
+    E.emu_transform_key_polys(O.p32(K.bk), C.c_int64(npolys), dptr(spec))
+    rng = np.random.default_rng(3)
+    acc = rng.integers(-2**31, 2**31, (2, 1024)).astype(np.int32)
+    for i, a in [(0, 5), (3, -1000), (7, 1023), (2, -1024), (15, 1)]:
+        ref = orc.mux_rotate(i, a, acc, schoolbook=True)
+        got = acc.copy()
+        E.emu_mux_rotate(dptr(spec), p.l, p.Bgbit, i, a, O.p32(got))
+        assert np.array_equal(ref, got)
+        acc = ref
+    x = K.encrypt_bits([1], 2.0**-15, 3)[0]
+    ref = orc.bootstrap_wo_keyswitch(x)
+    bara = np.array([O.lib().oracle_modswitch(int(v), 1024) for v in x[:p.n]], np.int32)
+    barb = O.lib().oracle_modswitch(int(x[p.n]), 1024)
+    out = np.zeros(1025, np.int32)
+    E.emu_blind_rotate(dptr(spec), p.n, p.l, p.Bgbit, O.p32(bara), barb, 1 << 29, O.p32(out))
+    assert np.array_equal(ref, out)
+
+
+def test_cmux_l2_bgbit10(E, O):
+    # the SK-80 shape (l = 2, Bgbit = 10) exercises the largest digits the Torus32 engine accepts
+    p = O.make_params("SK-80", n=4)
+    K = O.SKKeys(p, 5, 9.0e-9, 2.44e-5)
+    orc = O.Oracle(p, K.bk, K.ksk)
+    npolys = K.bk.size // 1024
+    spec = np.zeros(npolys * 2 * 512 * 2, np.float64)
+    E.emu_transform_key_polys(O.p32(K.bk), C.c_int64(npolys), dptr(spec))
+    acc = np.random.default_rng(4).integers(-2**31, 2**31, (2, 1024)).astype(np.int32)
+    ref = orc.mux_rotate(1, 777, acc, schoolbook=True)
+    got = acc.copy()
+    E.emu_mux_rotate(dptr(spec), p.l, p.Bgbit, 1, 777, O.p32(got))
+    assert np.array_equal(ref, got)

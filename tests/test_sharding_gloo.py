@@ -1,0 +1,61 @@
+"""N > 1 path of bench.py rehearsed on CPU: two gloo ranks run the rank-sharding / barrier / max-over-ranks logic
+(bench.dist_setup) and the per-rank input derivation; no GPU and no oracle involved."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_gloo_barrier_and_max_reduce(tmp_path):
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent(f"""
+        import json, os, sys, time
+        sys.path.insert(0, {ROOT!r})
+        os.environ["THFHE_BENCH_BACKEND"] = "gloo"
+        import bench
+        rank, world, barrier, max_reduce, backend = bench.dist_setup(2)
+        barrier()
+        t = max_reduce(1.0 + rank)          # slowest rank defines the step time
+        import numpy as np
+        rng = np.random.default_rng(0x5EED0002 + rank)   # per-rank synthetic inputs are disjoint streams
+        first = int(rng.integers(0, 2**31))
+        barrier()
+        print(json.dumps(dict(rank=rank, world=world, t=t, backend=backend, first=first)), flush=True)
+    """))
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for pr in procs:
+        so, se = pr.communicate(timeout=240)
+        assert pr.returncode == 0, se
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    assert sorted(o["rank"] for o in outs) == [0, 1]
+    assert all(o["world"] == 2 and o["backend"] == "gloo" and o["t"] == 2.0 for o in outs)
+    assert outs[0]["first"] != outs[1]["first"]
+
+
+def test_algorithmic_bytes_match_baseline_md():
+    # BASELINE.md section 3 table
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "torus-fhe_amd"))
+    import bench
+    import thfhe
+    exp = {"SK-128": (61931520, 20676608, 82615700), "SK-80": (32768000, 16416768, 49190780),
+           "SK-lib": (100663296, 33587200, 134262796), "MK2": (68157440, 12804096, 80974028),
+           "MK4": (200540160, 41861120, 242425772)}
+    for name, (bk, ksk, total) in exp.items():
+        ab = bench.algorithmic_bytes(thfhe.make_params(name))
+        assert (ab["bk"], ab["ksk"], ab["total"]) == (bk, ksk, total), name

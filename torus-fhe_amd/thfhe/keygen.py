@@ -1,0 +1,215 @@
+"""Host-side synthetic key generation, encryption and decryption for the bootstrapping engine.
+
+Mirrors the reference constructors that produce the hot path's inputs (they run once, on the host):
+  LweKey / RLweKey                      lwe.jl:11-19, rlwe.jl:12-30
+  BootstrapKey (coefficient domain)     bootstrap.jl:6-15 -> tgsw_encrypt tgsw.jl:88-101 -> rlwe_encrypt_zero rlwe.jl:79-105
+  KeyswitchKey                          keyswitch.jl:14-41 (noise recentred over the whole table)
+  lwe_encrypt / lwe_phase               lwe.jl:38-59
+  3-gen multi-key material              multikey_3gen.jl:15-30, mk_internals.jl:120-137,209-298, tgsw_3gen.jl:41-95
+Randomness is numpy's PCG64 (the reference uses Julia's MersenneTwister, whose stream is not
+reproducible outside Julia); the hot path itself consumes no randomness.  Ring products with the
+small secret polynomials are computed EXACTLY with float64 GEMMs on <= 22-bit limbs (all partial
+sums stay below 2^53), then reduced mod 2^32 / 2^64.
+"""
+import numpy as np
+
+from . import MU8
+
+
+def dtot32(d):
+    """numeric-functions.jl:101-103: trunc(Int32, d * 2^32) (wrapping)."""
+    return np.trunc(np.asarray(d, np.float64) * 4294967296.0).astype(np.int64).astype(np.uint32).view(np.int32)
+
+
+def dtot64(d):
+    """numeric-functions.jl:105-107 (|d| << 0.5 here, so the int64 conversion cannot overflow)."""
+    return np.trunc(np.asarray(d, np.float64) * 18446744073709551616.0).astype(np.int64)
+
+
+def negacyclic_matrix(z):
+    """M[j, q] with (a (*) z)[q] = sum_j a[j] M[j, q]  (product mod X^N + 1), z small integers."""
+    z = np.asarray(z, np.float64)
+    N = z.shape[0]
+    j = np.arange(N)[:, None]
+    q = np.arange(N)[None, :]
+    return z[(q - j) % N] * np.where(q >= j, 1.0, -1.0)
+
+
+def polymul_small32(a, z):
+    """rows of a (int32 torus polynomials) times the small polynomial z, exact mod 2^32."""
+    M = negacyclic_matrix(z)
+    a = np.ascontiguousarray(a, np.int32).astype(np.int64)
+    lo, hi = (a & 0xFFFF).astype(np.float64), (a >> 16).astype(np.float64)
+    r = (lo @ M).astype(np.int64) + ((hi @ M).astype(np.int64) << 16)
+    return r.astype(np.uint32).view(np.int32)
+
+
+def polymul_small64(a, z):
+    """rows of a (int64 torus polynomials) times the small polynomial z, exact mod 2^64 (3 x 22-bit limbs)."""
+    M = negacyclic_matrix(z)
+    a = np.ascontiguousarray(a, np.int64).view(np.uint64)
+    out = np.zeros(a.shape, np.uint64)
+    for sh in (0, 22, 44):
+        limb = ((a >> np.uint64(sh)) & np.uint64((1 << 22) - 1)).astype(np.float64)
+        out += (limb @ M).astype(np.int64).view(np.uint64) << np.uint64(sh)
+    return out.view(np.int64)
+
+
+def gen_keyswitch_key(rng, in_key, out_key, t, basebit, sigma):
+    """keyswitch.jl:14-41 -> int32[len(in_key)][t][base-1][n+1]."""
+    in_key = np.asarray(in_key, np.int64)
+    out_key = np.asarray(out_key, np.int32)
+    Nin, n, base = in_key.shape[0], out_key.shape[0], 1 << basebit
+    noise = rng.standard_normal((Nin, t, base - 1)) * sigma
+    noise -= noise.mean()
+    ksk = np.empty((Nin, t, base - 1, n + 1), np.int32)
+    a = rng.integers(-2**31, 2**31, size=(Nin, t, base - 1, n), dtype=np.int64)
+    ksk[..., :n] = a.astype(np.int32)
+    h = np.arange(1, base, dtype=np.int64)[None, None, :]
+    j = np.arange(1, t + 1, dtype=np.int64)[None, :, None]
+    msg = (in_key[:, None, None] * h) << (32 - j * basebit)
+    s = out_key.astype(np.float64)
+    dot = ((a & 0xFFFF).astype(np.float64) @ s).astype(np.int64) + (((a >> 16).astype(np.float64) @ s).astype(np.int64) << 16)
+    b = msg + dtot32(noise).astype(np.int64) + dot
+    ksk[..., n] = b.astype(np.uint32).view(np.int32)
+    return ksk
+
+
+class SecretKeySet:
+    """Single-key secret material + the cloud-key tables the engine consumes."""
+
+    def __init__(self, params, seed=0x5EED0001, sigma_lwe=2.0**-15, sigma_bk=2.0**-25, sigma_ks=2.0**-15, lwe_key=None):
+        p = self.params = params
+        assert p.k == 1 and p.torus_bits == 32 and p.parties == 1
+        rng = np.random.default_rng(seed)
+        self.sigma_lwe = sigma_lwe
+        self.lwe_key = (np.asarray(lwe_key, np.int32) if lwe_key is not None
+                        else rng.integers(0, 2, p.n).astype(np.int32))          # LweKey: uniform binary
+        self.rlwe_key = rng.integers(0, 2, p.N).astype(np.int32)                 # RLweKey: uniform binary
+        rows = 2 * p.l
+        # rlwe_encrypt_zero for every TGSW row: mask uniform, body = z (*) mask + gaussian
+        mask = rng.integers(-2**31, 2**31, size=(p.n * rows, p.N), dtype=np.int64).astype(np.int32)
+        body = polymul_small32(mask, self.rlwe_key).astype(np.int64) + dtot32(rng.standard_normal((p.n * rows, p.N)) * sigma_bk)
+        bk = np.empty((p.n, rows, 2, p.N), np.int64)
+        bk[:, :, 0, :] = mask.reshape(p.n, rows, p.N)
+        bk[:, :, 1, :] = body.reshape(p.n, rows, p.N)
+        # + message * gadget on the constant coefficient of polynomial j of row (j, level)   tgsw.jl:65-85
+        for j in range(2):
+            for lv in range(p.l):
+                bk[:, j * p.l + lv, j, 0] += self.lwe_key.astype(np.int64) << (32 - (lv + 1) * p.Bgbit)
+        self.bk = bk.astype(np.uint32).view(np.int32)
+        self.ksk = gen_keyswitch_key(rng, self.rlwe_key, self.lwe_key, p.ks_t, p.ks_basebit, sigma_ks)
+
+    def encrypt(self, bits, seed=0x5EED0002):
+        """lwe_encrypt of +-1/8 per bit -> int32[len(bits)][n+1]."""
+        bits = np.asarray(bits).astype(bool)
+        rng = np.random.default_rng(seed)
+        p = self.params
+        a = rng.integers(-2**31, 2**31, size=(bits.shape[0], p.n), dtype=np.int64)
+        e = dtot32(rng.standard_normal(bits.shape[0]) * self.sigma_lwe).astype(np.int64)
+        mu = np.where(bits, MU8, -MU8).astype(np.int64)
+        b = mu + e + (a * self.lwe_key.astype(np.int64)).sum(axis=1)
+        out = np.empty((bits.shape[0], p.n + 1), np.int32)
+        out[:, :p.n] = a.astype(np.int32)
+        out[:, p.n] = b.astype(np.uint32).view(np.int32)
+        return out
+
+    def phase(self, recs):
+        """lwe_phase = b - <a, s> as wrapping int32."""
+        recs = np.asarray(recs, np.int32).reshape(-1, self.params.n + 1).astype(np.int64)
+        ph = recs[:, -1] - (recs[:, :-1] * self.lwe_key.astype(np.int64)).sum(axis=1)
+        return ph.astype(np.uint32).view(np.int32)
+
+    def decrypt(self, recs):
+        return self.phase(recs) > 0
+
+
+def rand_ternary(rng, shape):
+    """rand_negative_binary, numeric-functions.jl:11-13: P(+-1) = 0.113546097609674."""
+    u = rng.random(shape)
+    return np.where(u < 0.113546097609674, -1, np.where(u < 2 * 0.113546097609674, 1, 0)).astype(np.int64)
+
+
+class MKSecretKeySet:
+    """3-gen multi-key material following 3-gen-mk-tfhe/multikey_3gen.jl:15-30."""
+
+    def __init__(self, params, seed=0x5EED0001, sigma_lwe=None, sigma_bk=2.0**-30.70, sigma_ks=None):
+        p = self.params = params
+        assert p.k == 1 and p.torus_bits == 64
+        rng = np.random.default_rng(seed)
+        P, n, N, l = p.parties, p.n, p.N, p.l
+        self.sigma_lwe = sigma_lwe if sigma_lwe is not None else 2.0**-13.52
+        sigma_ks = sigma_ks if sigma_ks is not None else self.sigma_lwe
+        self.lwe_keys = rng.integers(0, 2, (P, n)).astype(np.int32)          # SecretKey_3gen
+        self.rlwe_keys = rand_ternary(rng, (P, N))                            # RLweKey(rng, params, true)
+        crp = rng.integers(-2**63, 2**63, size=N, dtype=np.int64)             # CRP_3gen(a_same = true)
+        # PublicKey b_q[i] = z_q (*) a + e ; CommonPubKey B[i] = sum_q b_q[i]
+        B = np.zeros((l, N), np.uint64)
+        for q in range(P):
+            za = polymul_small64(crp[None, :], self.rlwe_keys[q])[0].view(np.uint64)
+            B += za[None, :] + dtot64(rng.standard_normal((l, N)) * sigma_bk).view(np.uint64)
+        # tgsw_encrypt_3gen for every key bit
+        bk = np.empty((P, n, 4, l, N), np.uint64)
+        g = [np.uint64(64 - (lv + 1) * p.Bgbit) for lv in range(l)]
+        for lv in range(l):
+            r1 = rand_ternary(rng, (P * n, N))
+            r2 = rand_ternary(rng, (P * n, N))
+            MB = negacyclic_matrix_u64(B[lv])
+            MA = negacyclic_matrix_u64(crp.view(np.uint64))
+            e = [dtot64(rng.standard_normal((P * n, N)) * sigma_bk).view(np.uint64) for _ in range(4)]
+            m = self.lwe_keys.reshape(-1).astype(np.uint64)
+            P1 = small_times_torus64(r1, MB) + e[0]
+            P2 = small_times_torus64(r2, MB) + e[1]
+            P3 = small_times_torus64(r2, MA) + e[2]
+            P4 = small_times_torus64(r1, MA) + e[3]
+            P1[:, 0] += m << g[lv]
+            P3[:, 0] += m << g[lv]
+            for part, arr in enumerate((P1, P2, P3, P4)):
+                bk[:, :, part, lv, :] = arr.reshape(P, n, N)
+        self.bk = bk.view(np.int64)
+        self.ksk = np.stack([gen_keyswitch_key(rng, self.rlwe_keys[q], self.lwe_keys[q], p.ks_t, p.ks_basebit, sigma_ks)
+                             for q in range(P)])
+
+    def encrypt(self, bits, seed=0x5EED0002):
+        """mk_encrypt_3gen, mk_api.jl:519-536 -> int32[len(bits)][P*n+1]."""
+        bits = np.asarray(bits).astype(bool)
+        rng = np.random.default_rng(seed)
+        p = self.params
+        W = p.n * p.parties
+        a = rng.integers(-2**31, 2**31, size=(bits.shape[0], W), dtype=np.int64)
+        e = dtot32(rng.standard_normal(bits.shape[0]) * self.sigma_lwe).astype(np.int64)
+        mu = np.where(bits, MU8, -MU8).astype(np.int64)
+        b = mu + e + (a * self.lwe_keys.reshape(-1).astype(np.int64)).sum(axis=1)
+        out = np.empty((bits.shape[0], W + 1), np.int32)
+        out[:, :W] = a.astype(np.int32)
+        out[:, W] = b.astype(np.uint32).view(np.int32)
+        return out
+
+    def phase(self, recs):
+        """mk_lwe_phase, mk_internals.jl:85-91."""
+        W = self.params.n * self.params.parties
+        recs = np.asarray(recs, np.int32).reshape(-1, W + 1).astype(np.int64)
+        ph = recs[:, -1] - (recs[:, :-1] * self.lwe_keys.reshape(-1).astype(np.int64)).sum(axis=1)
+        return ph.astype(np.uint32).view(np.int32)
+
+    def decrypt(self, recs):
+        return self.phase(recs) > 0
+
+
+def negacyclic_matrix_u64(b):
+    """Three float64 limb matrices of the torus polynomial b: small (*) b = sum_limb (small @ M_limb) << shift."""
+    b = np.asarray(b).view(np.uint64)
+    mats = []
+    for sh in (0, 22, 44):
+        limb = ((b >> np.uint64(sh)) & np.uint64((1 << 22) - 1)).astype(np.float64)
+        mats.append((negacyclic_matrix(limb), np.uint64(sh)))
+    return mats
+
+
+def small_times_torus64(small, mats):
+    """rows of small-coefficient polynomials (|s| <= 1) times the torus polynomial behind `mats`, exact mod 2^64."""
+    s = np.asarray(small, np.float64)
+    out = np.zeros(s.shape, np.uint64)
+    for M, sh in mats:
+        out += (s @ M).astype(np.int64).view(np.uint64) << sh
+    return out
