@@ -173,11 +173,15 @@ class CloudKey:
         self.words = p.n + 1
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().thfhe_ctx_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.thfhe_ctx_destroy(self.h)
+        self.h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter teardown
+            pass
 
     # -- host-buffer calls -------------------------------------------------------------------------
     def gates(self, op, x, y=None, z=None):
