@@ -28,6 +28,27 @@ struct Wave {
         for (int l = 0; l < 64; l++) inv_seg3(l, z[l], xbuf, T1);
     }
 };
+struct WaveS {  // the LDS-ring kernel's variant: swizzled 512-slot buffer, pass-2 twiddles as powers
+    cplx T1[512], T2[64];
+    cplx xbuf[512];
+    W64 w[64];
+    WaveS() {
+        make_twiddles_1024(T1, T2);
+        for (int l = 0; l < 64; l++) w[l] = W64{T2[1 * 8 + (l & 7)], T2[2 * 8 + (l & 7)], T2[4 * 8 + (l & 7)]};
+    }
+    void fwd(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) fwds_seg1(l, z[l], xbuf, T1);
+        for (int l = 0; l < 64; l++) fwds_seg2_ld(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) fwds_seg2_st(l, z[l], xbuf, w[l]);
+        for (int l = 0; l < 64; l++) fwds_seg3(l, z[l], xbuf);
+    }
+    void inv(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) invs_seg1(l, z[l], xbuf, w[l]);
+        for (int l = 0; l < 64; l++) invs_seg2_ld(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) invs_seg2_st(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) invs_seg3(l, z[l], xbuf, T1);
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -149,5 +170,40 @@ void emu_inv_raw(const double *in, double *zout) {
             zout[2 * (l + 64 * m)] = z[l][m].re;
             zout[2 * (l + 64 * m) + 1] = z[l][m].im;
         }
+}
+}
+
+extern "C" {
+// swizzled-variant transforms must give the same spectra (same register order) as the padded variant, and the same
+// exact products: forward with one variant, inverse with the other.
+double emu_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out) {
+    Wave w;
+    WaveS ws;
+    std::vector<double> spec(2 * 512 * 2);
+    emu_transform_key_polys(b, 1, spec.data());   // key transformed by the padded variant
+    const cplx *B = reinterpret_cast<const cplx *>(spec.data());
+    static cplx z[64][8], z2[64][8], slo[64][8], shi[64][8];
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) z2[l][m] = z[l][m] = cplx{(double)small[l + 64 * m], (double)small[l + 64 * m + 512]};
+    ws.fwd(z);   // digits transformed by the swizzled variant
+    w.fwd(z2);
+    double dmax = 0;
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) {
+            double d = __builtin_fabs(z[l][m].re - z2[l][m].re) + __builtin_fabs(z[l][m].im - z2[l][m].im);
+            if (d > dmax) dmax = d;
+        }
+    memset(slo, 0, sizeof(slo));
+    memset(shi, 0, sizeof(shi));
+    for (int l = 0; l < 64; l++) {
+        mac8(l, slo[l], z[l], B);
+        mac8(l, shi[l], z[l], B + 512);
+    }
+    ws.inv(slo);
+    ws.inv(shi);
+    std::vector<int32_t> acc(1024, 0);
+    for (int l = 0; l < 64; l++) acc_update16(l, acc.data(), slo[l], shi[l]);
+    memcpy(out, acc.data(), sizeof(int32_t) * 1024);
+    return dmax;
 }
 }

@@ -29,10 +29,11 @@ inline int ilog2(int x) {
 #if defined(__HIPCC__)
 // Wave-level ordering point between two LDS segments.  One wavefront's DS instructions execute in issue order,
 // so no hardware barrier is needed -- this only stops the compiler from moving LDS accesses across the exchange.
+// The fences are scoped to the LDS address space so that global (bootstrapping-key) loads may be scheduled across them.
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 // forward / inverse folded negacyclic transform of the 8 points each lane holds (see thfhe_lane.h)

@@ -115,9 +115,12 @@ THFHE_FN void fwd_seg2_st(int lane, cplx (&z)[8], cplx *xbuf, const cplx *T2) {
 #pragma unroll
     for (int k1 = 1; k1 < 8; k1++) xbuf[xs_c(k1, lane)] = cmul(z[k1], T2[k1 * 8 + (lane & 7)]);
 }
-THFHE_FN void fwd_seg3(int lane, cplx (&z)[8], const cplx *xbuf) {
+THFHE_FN void fwd_seg3_ld(int lane, cplx (&z)[8], const cplx *xbuf) {
 #pragma unroll
     for (int j0 = 0; j0 < 8; j0++) z[j0] = xbuf[xs_d(j0, lane)];
+}
+THFHE_FN void fwd_seg3(int lane, cplx (&z)[8], const cplx *xbuf) {
+    fwd_seg3_ld(lane, z, xbuf);
     dft8<+1>(z);
 }
 
@@ -137,9 +140,93 @@ THFHE_FN void inv_seg2_st(int lane, cplx (&z)[8], cplx *xbuf) {
 #pragma unroll
     for (int j1 = 0; j1 < 8; j1++) xbuf[xs_b(j1, lane)] = z[j1];
 }
+THFHE_FN void inv_seg3_ld(int lane, cplx (&z)[8], const cplx *xbuf) {
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) z[k0] = xbuf[xs_a(k0, lane)];
+}
+THFHE_FN void inv_seg3_fin(int lane, cplx (&z)[8], const cplx *T1) {
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) z[k0] = cmul_conj(z[k0], T1[k0 * 64 + lane]);
+    dft8<-1>(z);
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+}
 THFHE_FN void inv_seg3(int lane, cplx (&z)[8], const cplx *xbuf, const cplx *T1) {
 #pragma unroll
     for (int k0 = 0; k0 < 8; k0++) z[k0] = cmul_conj(xbuf[xs_a(k0, lane)], T1[k0 * 64 + lane]);
+    dft8<-1>(z);
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+}
+
+// ---- variant with an unpadded, XOR-swizzled 512-slot transpose buffer and pass-2 twiddles as powers of one per-lane
+// root w = exp(2 pi i (lane & 7) / 64) (w, w^2, w^4 held in registers; w^3, w^5, w^6, w^7 by one product each).
+// Used by the LDS-ring kernel, whose 160 KiB LDS budget has no room for padding or for the T2 table.
+//   transpose 1: column (j1*8 + j0) of row k0 is XORed with 8*(k0 & 1);
+//   transpose 2: column (k1*8 + (j0 ^ k1)) of row k0 is XORed with 8*((k0 >> 1) & 1)          
+THFHE_FN int ys_a(int k0, int lane) { return k0 * 64 + (lane ^ ((k0 & 1) << 3)); }
+THFHE_FN int ys_b(int j1, int lane) { return (lane >> 3) * 64 + ((j1 * 8 + (lane & 7)) ^ (((lane >> 3) & 1) << 3)); }
+THFHE_FN int ys_c(int k1, int lane) { return (lane >> 3) * 64 + ((k1 * 8 + ((lane & 7) ^ k1)) ^ (((lane >> 4) & 1) << 3)); }
+THFHE_FN int ys_d(int j0, int lane) { return (lane >> 3) * 64 + (((lane & 7) * 8 + (j0 ^ (lane & 7))) ^ (((lane >> 4) & 1) << 3)); }
+
+struct W64 {  // per-lane powers of w = omega_64^(lane & 7)
+    cplx w1, w2, w4;
+};
+THFHE_FN void w64_powers(const W64 &w, cplx (&p)[8]) {
+    p[0] = cplx{1.0, 0.0};
+    p[1] = w.w1;
+    p[2] = w.w2;
+    p[3] = cmul(w.w1, w.w2);
+    p[4] = w.w4;
+    p[5] = cmul(w.w1, w.w4);
+    p[6] = cmul(w.w2, w.w4);
+    p[7] = cmul(p[3], w.w4);
+}
+
+THFHE_FN void fwds_seg1(int lane, cplx (&z)[8], cplx *xbuf, const cplx *T1) {
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+    dft8<+1>(z);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) xbuf[ys_a(k0, lane)] = cmul(z[k0], T1[k0 * 64 + lane]);
+}
+THFHE_FN void fwds_seg2_ld(int lane, cplx (&z)[8], const cplx *xbuf) {
+#pragma unroll
+    for (int j1 = 0; j1 < 8; j1++) z[j1] = xbuf[ys_b(j1, lane)];
+}
+THFHE_FN void fwds_seg2_st(int lane, cplx (&z)[8], cplx *xbuf, const W64 &w) {
+    dft8<+1>(z);
+    cplx p[8];
+    w64_powers(w, p);
+    xbuf[ys_c(0, lane)] = z[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) xbuf[ys_c(k1, lane)] = cmul(z[k1], p[k1]);
+}
+THFHE_FN void fwds_seg3(int lane, cplx (&z)[8], const cplx *xbuf) {
+#pragma unroll
+    for (int j0 = 0; j0 < 8; j0++) z[j0] = xbuf[ys_d(j0, lane)];
+    dft8<+1>(z);
+}
+THFHE_FN void invs_seg1(int lane, cplx (&z)[8], cplx *xbuf, const W64 &w) {
+    dft8<-1>(z);
+    cplx p[8];
+    w64_powers(w, p);
+    xbuf[ys_d(0, lane)] = z[0];
+#pragma unroll
+    for (int j0 = 1; j0 < 8; j0++) xbuf[ys_d(j0, lane)] = cmul_conj(z[j0], p[j0]);
+}
+THFHE_FN void invs_seg2_ld(int lane, cplx (&z)[8], const cplx *xbuf) {
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) z[k1] = xbuf[ys_c(k1, lane)];
+}
+THFHE_FN void invs_seg2_st(int lane, cplx (&z)[8], cplx *xbuf) {
+    dft8<-1>(z);
+#pragma unroll
+    for (int j1 = 0; j1 < 8; j1++) xbuf[ys_b(j1, lane)] = z[j1];
+}
+THFHE_FN void invs_seg3(int lane, cplx (&z)[8], const cplx *xbuf, const cplx *T1) {
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) z[k0] = cmul_conj(xbuf[ys_a(k0, lane)], T1[k0 * 64 + lane]);
     dft8<-1>(z);
 #pragma unroll
     for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
@@ -211,6 +298,18 @@ THFHE_FN void mac8(int lane, cplx (&S)[8], const cplx (&z)[8], const cplx *B) {
         cplx b = B[m * 64 + lane];
         S[m].re += z[m].re * b.re - z[m].im * b.im;
         S[m].im += z[m].re * b.im + z[m].im * b.re;
+    }
+}
+// register-resident key chunk: b[m] = B[m*64 + lane]; S[m] += z[m] * b[m]
+THFHE_FN void load8(int lane, cplx (&b)[8], const cplx *B) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) b[m] = B[m * 64 + lane];
+}
+THFHE_FN void mac8r(cplx (&S)[8], const cplx (&z)[8], const cplx (&b)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        S[m].re += z[m].re * b[m].re - z[m].im * b[m].im;
+        S[m].im += z[m].re * b[m].im + z[m].im * b[m].re;
     }
 }
 // acc_poly[q] += round(lo) + (round(hi) << 16)  for the 16 coefficients this lane owns

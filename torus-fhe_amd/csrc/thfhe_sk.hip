@@ -11,6 +11,7 @@
 //   sk_linear_kernel          NOT / COPY (J/gates.jl:76-79)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <string>
@@ -113,7 +114,7 @@ struct BRArgs {
     int32_t mu;
 };
 
-template <int L>
+template <int L, int ABL>
 __global__ __launch_bounds__(256, 2) void sk_blind_rotate_kernel(BRArgs a) {
     __shared__ cplx sT1[512];
     __shared__ cplx sT2[64];
@@ -156,11 +157,23 @@ __global__ __launch_bounds__(256, 2) void sk_blind_rotate_kernel(BRArgs a) {
                 cplx z[8];
                 digits_to_z(t, p, Bgbit, z);
                 wave_fft_fwd(lane, z, xb, sT1, sT2);
-                const cplx *B = a.bk + bk_spec_index(i, j * L + (p - 1), 0, 0, 2 * L);
-                mac8(lane, S[0][0], z, B);
-                mac8(lane, S[0][1], z, B + 512);
-                mac8(lane, S[1][0], z, B + 1024);
-                mac8(lane, S[1][1], z, B + 1536);
+                if (ABL == 2) {  // ablation: no key traffic at all (results meaningless)
+#pragma unroll
+                    for (int c = 0; c < 2; c++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+#pragma unroll
+                            for (int m = 0; m < 8; m++) {
+                                S[c][h][m].re += z[m].re * z[(m + c) & 7].re - z[m].im * z[(m + h) & 7].im;
+                                S[c][h][m].im += z[m].re * z[(m + h) & 7].im + z[m].im * z[(m + c) & 7].re;
+                            }
+                } else {
+                    const cplx *B = a.bk + bk_spec_index(ABL == 1 ? 0 : i, j * L + (p - 1), 0, 0, 2 * L);  // ABL 1: key index pinned (L1-resident)
+                    mac8(lane, S[0][0], z, B);
+                    mac8(lane, S[0][1], z, B + 512);
+                    mac8(lane, S[1][0], z, B + 1024);
+                    mac8(lane, S[1][1], z, B + 1536);
+                }
             }
         }
         wave_sync();  // every rotated read of acc precedes the updates below
@@ -173,6 +186,238 @@ __global__ __launch_bounds__(256, 2) void sk_blind_rotate_kernel(BRArgs a) {
         wave_sync();
     }
     extract16(lane, acc, acc + 1024, a.out + job * 1025);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// blind rotate + extract, variant 2 ("one wave per SIMD"): one 64-thread workgroup = one wavefront = one job, the
+// whole 512-entry register budget.  rocprof + ablation of variant 1 showed the per-wave key loads through the
+// vector-memory path, not the arithmetic, set its pace (profiles/r01_summary.md).  Here every key chunk is requested
+// a full pipeline stage (>1000 cycles) before its use and held in registers, and the forward transform of digit
+// row r+1 (VALU + LDS exchanges) is interleaved with the multiply-accumulate of row r (VALU only), so the LDS
+// round trips of one hide behind the FMAs of the other.  The two limbs of an output column are inverse-transformed
+// side by side through two transpose buffers.  35 840 B LDS per workgroup -> 4 workgroups (one per SIMD) per CU.
+// ------------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(64, 1) void sk_blind_rotate_w1_kernel(BRArgs a) {
+    __shared__ cplx sT1[512];
+    __shared__ cplx sT2[64];
+    __shared__ int32_t acc[2048];
+    __shared__ cplx xb0[kXbufSlots];
+    __shared__ cplx xb1[kXbufSlots];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 8; t++) sT1[t * 64 + lane] = a.tw[t * 64 + lane];
+    sT2[lane] = a.tw[512 + lane];
+    const long job = blockIdx.x;
+    const int32_t *bara = a.bara + job * a.n_pad;
+    const int Bgbit = a.Bgbit;
+    const uint32_t offset = decomp_offset32(L, Bgbit);
+    constexpr int ROWS = 2 * L;
+    acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
+    wave_sync();
+
+    for (int i = 0; i < a.n; i++) {
+        const int ai = bara[i];  // wave-uniform
+        if (ai == 0) continue;   // J/bootstrap.jl:40
+        const int a2n = ai & 2047;
+        const cplx *Bi = a.bk + bk_spec_index(i, 0, 0, 0, ROWS);
+        cplx S[2][2][8];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
+        cplx B[4][8];   // the four (column, limb) chunks of the row being multiplied
+        cplx zf[8];     // row in the forward transform
+        cplx zm[8];     // transformed row being multiplied
+        uint32_t t[16];
+
+        // stage 0: request row 0's key chunks, transform row 0
+#pragma unroll
+        for (int q = 0; q < 4; q++) load8(lane, B[q], Bi + q * 512);
+        load_rotated16(lane, acc, a2n, offset, t);
+        digits_to_z(t, 1, Bgbit, zf);
+        wave_fft_fwd(lane, zf, xb0, sT1, sT2);
+
+        // stages 1 .. ROWS-1: transform row s while multiplying row s-1; refill each chunk right after its use
+#pragma unroll
+        for (int s = 1; s < ROWS; s++) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) zm[m] = zf[m];
+            if (s == L) load_rotated16(lane, acc + 1024, a2n, offset, t);
+            digits_to_z(t, (s % L) + 1, Bgbit, zf);
+            const cplx *Bs = Bi + (size_t)s * 2048;
+            wave_sync();
+            fwd_seg1(lane, zf, xb0, sT1);
+            wave_sync();
+            fwd_seg2_ld(lane, zf, xb0);
+            mac8r(S[0][0], zm, B[0]);
+            load8(lane, B[0], Bs);
+            fwd_seg2_st(lane, zf, xb0, sT2);
+            wave_sync();
+            fwd_seg3_ld(lane, zf, xb0);
+            mac8r(S[0][1], zm, B[1]);
+            load8(lane, B[1], Bs + 512);
+            mac8r(S[1][0], zm, B[2]);
+            load8(lane, B[2], Bs + 1024);
+            dft8<+1>(zf);
+            mac8r(S[1][1], zm, B[3]);
+            load8(lane, B[3], Bs + 1536);
+        }
+        // drain: multiply the last row
+        mac8r(S[0][0], zf, B[0]);
+        mac8r(S[0][1], zf, B[1]);
+        mac8r(S[1][0], zf, B[2]);
+        mac8r(S[1][1], zf, B[3]);
+
+        wave_sync();  // every rotated read of acc precedes the updates below
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            inv_seg1(lane, S[c][0], xb0, sT2);
+            inv_seg1(lane, S[c][1], xb1, sT2);
+            wave_sync();
+            inv_seg2_ld(lane, S[c][0], xb0);
+            inv_seg2_ld(lane, S[c][1], xb1);
+            inv_seg2_st(lane, S[c][0], xb0);
+            inv_seg2_st(lane, S[c][1], xb1);
+            wave_sync();
+            inv_seg3_ld(lane, S[c][0], xb0);
+            inv_seg3_ld(lane, S[c][1], xb1);
+            inv_seg3_fin(lane, S[c][0], sT1);
+            inv_seg3_fin(lane, S[c][1], sT1);
+            acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
+            wave_sync();
+        }
+    }
+    extract16(lane, acc, acc + 1024, a.out + job * 1025);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// blind rotate + extract, variant 3 ("LDS ring"): the shipping kernel.
+//
+// One 512-thread workgroup = 8 wavefronts = 8 jobs, one workgroup per CU, all 160 KiB of LDS:
+//     T1 twiddles 8 KiB | 8 x (accumulator 8 KiB + transpose buffer 8 KiB) | key ring 3 x 8 KiB        = 163 840 B
+// The eight waves walk the key index i, the digit rows and the four (column, limb) chunks of a row in lock step.
+// A chunk is 8 KiB of key spectrum = 8 slices of 1 KiB; wave w brings slice w into the ring with ONE
+// global_load_lds_dwordx4 (LDS-DMA, no registers), so the whole key crosses the CU's vector-memory path once per
+// workgroup instead of once per wave (variant 1 was bound by exactly that path: profiles/r01_summary.md).
+// Hand-off of chunk q: every wave waits for its own slice (s_waitcnt vmcnt(N), N = younger DMAs in flight), then
+// s_barrier -- after it the chunk is complete AND everybody has finished reading chunk q-1, whose slot is refilled
+// at once with chunk q+2.  One extra barrier after a row's last chunk frees that slot before the next transform, so
+// three chunks are in flight under every forward transform.  Per row: 5 barriers, 4 DMA issues per wave.
+// A wave whose mod-switched mask word is 0 (J/bootstrap.jl:40) or that has no job still streams and synchronises.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ring_dma(const cplx *gptr_lane, uint32_t lds_byte_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds_byte_off) : "memory", "m0");
+}
+template <int VM>
+__device__ __forceinline__ void ring_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+}
+__device__ __forceinline__ void wave_fft_fwd_s(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
+    wave_sync();
+    fwds_seg1(lane, z, xb, T1);
+    wave_sync();
+    fwds_seg2_ld(lane, z, xb);
+    fwds_seg2_st(lane, z, xb, w);
+    wave_sync();
+    fwds_seg3(lane, z, xb);
+}
+__device__ __forceinline__ void wave_fft_inv_s(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
+    wave_sync();
+    invs_seg1(lane, z, xb, w);
+    wave_sync();
+    invs_seg2_ld(lane, z, xb);
+    invs_seg2_st(lane, z, xb);
+    wave_sync();
+    invs_seg3(lane, z, xb, T1);
+}
+
+template <int L>
+__global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) {
+    __shared__ cplx sT1[512];
+    __shared__ int32_t sAcc[8][2048];
+    __shared__ cplx sX[8][512];
+    __shared__ cplx sRing[3][512];
+    constexpr int ROWS = 2 * L;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    sT1[threadIdx.x] = a.tw[threadIdx.x];
+    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)], a.tw[512 + 2 * 8 + (lane & 7)], a.tw[512 + 4 * 8 + (lane & 7)]};
+    const long job = (long)blockIdx.x * 8 + wave;
+    const bool has_job = job < a.jobs;
+    int32_t *acc = sAcc[wave];
+    cplx *xb = sX[wave];
+    const int32_t *bara = a.bara + (has_job ? job : 0) * a.n_pad;
+    const int Bgbit = a.Bgbit;
+    const uint32_t offset = decomp_offset32(L, Bgbit);
+    if (has_job) acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
+
+    // key stream: chunk q lives at a.bk + q*512 (complex); this wave's slice is +wave*64, this lane's element +lane
+    const long total_chunks = (long)a.n * ROWS * 4;
+    const cplx *gsrc = a.bk + wave * 64 + lane;     // advances by 512 complex per issued chunk
+    long q_issue = 0;
+    int slot_issue = 0;
+    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sRing[0][0] + (uint32_t)wave * 1024u;
+    auto issue = [&]() {
+        ring_dma(gsrc, ring_base + (uint32_t)slot_issue * 8192u);
+        if (q_issue + 1 < total_chunks) {  // past the end the last chunk is re-requested: keeps the vmcnt pattern uniform
+            gsrc += 512;
+            q_issue++;
+        }
+        slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
+    };
+    __syncthreads();  // twiddles + accumulators visible; nothing in flight yet
+    issue();
+    issue();
+    issue();
+    int slot_use = 0;
+
+    for (int i = 0; i < a.n; i++) {
+        const int ai = bara[i];                      // wave-uniform
+        const bool active = has_job && ai != 0;      // J/bootstrap.jl:40
+        const int a2n = ai & 2047;
+        cplx S[2][2][8];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
+        uint32_t t[16];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            cplx z[8];
+            if (active) {
+                if (r % L == 0) load_rotated16(lane, acc + (r / L) * 1024, a2n, offset, t);
+                digits_to_z(t, (r % L) + 1, Bgbit, z);
+                wave_fft_fwd_s(lane, z, xb, sT1, w64);
+            }
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {
+                // publish chunk: own slice landed (c4 == 0: two younger DMAs in flight, else one), then everybody
+                if (c4 == 0) ring_barrier<2>(); else ring_barrier<1>();
+                if (c4 > 0) issue();  // the slot of the chunk consumed before this barrier is free
+                if (active) mac8(lane, S[c4 >> 1][c4 & 1], z, &sRing[slot_use][0]);
+                slot_use = slot_use == 2 ? 0 : slot_use + 1;
+            }
+            ring_barrier<2>();  // the row's last chunk is consumed by all: refill its slot before the next transform
+            issue();
+        }
+        if (active) {
+            wave_sync();  // every rotated read of acc precedes the updates below
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                wave_fft_inv_s(lane, S[c][0], xb, sT1, w64);
+                wave_fft_inv_s(lane, S[c][1], xb, sT1, w64);
+                acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
+            }
+            wave_sync();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+    if (has_job) extract16(lane, acc, acc + 1024, a.out + job * 1025);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -340,7 +585,19 @@ int ensure_stage(thfhe_ctx *c, size_t words) {
 template <int L>
 void launch_br(const BRArgs &a, hipStream_t s) {
     const unsigned blocks = (unsigned)((a.jobs + 3) / 4);
-    hipLaunchKernelGGL(sk_blind_rotate_kernel<L>, dim3(blocks), dim3(256), 0, s, a);
+    static const int abl = getenv("THFHE_ABLATE") ? atoi(getenv("THFHE_ABLATE")) : 0;  // developer timing experiments only
+    static const int variant = getenv("THFHE_BR_VARIANT") ? atoi(getenv("THFHE_BR_VARIANT")) : 3;
+    if (variant == 3 && abl == 0) {
+        hipLaunchKernelGGL(sk_blind_rotate_ring_kernel<L>, dim3((unsigned)((a.jobs + 7) / 8)), dim3(512), 0, s, a);
+        return;
+    }
+    if (variant == 2 && abl == 0) {
+        hipLaunchKernelGGL(sk_blind_rotate_w1_kernel<L>, dim3((unsigned)a.jobs), dim3(64), 0, s, a);
+        return;
+    }
+    if (abl == 1) hipLaunchKernelGGL((sk_blind_rotate_kernel<L, 1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (abl == 2) hipLaunchKernelGGL((sk_blind_rotate_kernel<L, 2>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((sk_blind_rotate_kernel<L, 0>), dim3(blocks), dim3(256), 0, s, a);
 }
 
 // rotations (prologue + blind rotate) of `jobs` = gates * rot_per_gate jobs into c->d_u
