@@ -207,3 +207,65 @@ double emu_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *o
     return dmax;
 }
 }
+
+extern "C" {
+// ---- 3-gen multi-key: key transform + one CMux, mirroring mk_blind_rotate_ring_kernel's data flow --------------------
+// bk: int64[P][n][4][l][1024] (coefficient domain) -> spectral stream [pi][r][h][o][m][lane], scaled by 1/512
+void emu_mk_transform_key(const int64_t *bk, long PN /* parties*n */, int l, double *spec) {
+    WaveS w;
+    const int rows = 2 * l;
+    static cplx z[4][64][8];
+    cplx *out = reinterpret_cast<cplx *>(spec);
+    for (long pi = 0; pi < PN; pi++)
+        for (int r = 0; r < rows; r++)
+            for (int o = 0; o < 2; o++) {
+                const int j = r / l, lv = r % l;
+                const int64_t *poly = bk + (((size_t)pi * 4 + mk_part_index(j, o)) * l + lv) * 1024;
+                for (int ln = 0; ln < 64; ln++) {
+                    cplx zz[4][8];
+                    key_limbs64_to_z(ln, poly, zz);
+                    for (int h = 0; h < 4; h++) memcpy(z[h][ln], zz[h], sizeof(zz[h]));
+                }
+                for (int h = 0; h < 4; h++) {
+                    w.fwd(z[h]);
+                    cplx *dst = out + mk_chunk_index(pi, r, h, o, rows) * 512;
+                    for (int ln = 0; ln < 64; ln++)
+                        for (int m = 0; m < 8; m++) dst[m * 64 + ln] = cplx{z[h][ln][m].re * (1.0 / 512), z[h][ln][m].im * (1.0 / 512)};
+                }
+            }
+}
+void emu_mk_mux_rotate(const double *spec, int l, int Bgbit, long pi, int barai, int64_t *acc /* [2][1024] */) {
+    WaveS w;
+    const cplx *BK = reinterpret_cast<const cplx *>(spec);
+    const int rows = 2 * l, a2n = barai & 2047;
+    const uint64_t offset = decomp_offset64(l, Bgbit);
+    static cplx S[2][64][4][8], z[64][8];
+    static uint32_t t[64][16];
+    memset(S, 0, sizeof(S));
+    for (int r = 0; r < rows; r++) {
+        if (r % l == 0)
+            for (int ln = 0; ln < 64; ln++) load_rotated16_hi(ln, acc + (r / l) * 1024, a2n, offset, t[ln]);
+        // digits of the 64-bit value with Bgbit bits per level are digits of its top 32 bits
+        for (int ln = 0; ln < 64; ln++) digits_to_z(t[ln], (r % l) + 1, Bgbit, z[ln]);
+        w.fwd(z);
+        for (int o = 0; o < 2; o++)
+            for (int h = 0; h < 4; h++)
+                for (int ln = 0; ln < 64; ln++) mac8(ln, S[o][ln][h], z[ln], BK + mk_chunk_index(pi, r, h, o, rows) * 512);
+    }
+    for (int o = 0; o < 2; o++) {
+        static cplx lim[4][64][8];
+        for (int h = 0; h < 4; h++) {
+            for (int ln = 0; ln < 64; ln++) memcpy(lim[h][ln], S[o][ln][h], sizeof(lim[h][ln]));
+            w.inv(lim[h]);
+        }
+        for (int ln = 0; ln < 64; ln++) {
+            cplx SS[4][8];
+            for (int h = 0; h < 4; h++) memcpy(SS[h], lim[h][ln], sizeof(SS[h]));
+            acc_update16_64(ln, acc + o * 1024, SS);
+        }
+    }
+}
+void emu_mk_extract(const int64_t *acc, int32_t *out) {
+    for (int ln = 0; ln < 64; ln++) extract16_64(ln, acc, acc + 1024, out);
+}
+}

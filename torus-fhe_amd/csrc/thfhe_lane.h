@@ -28,6 +28,7 @@
 #ifndef THFHE_LANE_H
 #define THFHE_LANE_H
 
+#include <limits.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -352,6 +353,101 @@ THFHE_FN void key_limbs_to_z(int lane, const int32_t *poly, cplx (&zlo)[8], cplx
         zlo[m] = cplx{l0, l1};
         zhi[m] = cplx{h0, h1};
     }
+}
+
+
+// ---- 3-gen multi-key building blocks (Torus64 ring, k = 1)        J/tgsw_3gen.jl:102-113, J/3gen_mk_internals.jl:59-95 ----
+// Accumulator acc = [c1 (mask), c0 (body)] as int64[2][1024].  Digit rows r = j*l + lv: j = 0 digits of c1, j = 1 digits
+// of c0.  Outputs o = 0: c1' = sum g(c0) P4 + g(c1) P3 ; o = 1: c0' = sum g(c0) P1 + g(c1) P2.  Every key polynomial is
+// split into four balanced 16-bit limbs.  Spectral key stream order: [party][i][row r][limb h][output o][slot m][lane],
+// one 8 KiB chunk per (party, i, r, h, o).
+THFHE_FN int mk_part_index(int j, int o) {  // which of part_1..part_4 (0..3) multiplies digit set j for output o
+    return o == 0 ? (j == 0 ? 2 : 3) : (j == 0 ? 1 : 0);
+}
+THFHE_FN size_t mk_chunk_index(long pi /* party*n + i */, int r, int h, int o, int rows) {
+    return ((((size_t)pi * rows + r) * 4 + h) * 2 + o);  // * 512 complex
+}
+THFHE_FN uint64_t rot_minus_self64(const int64_t *p, int q, int a2n) {
+    int e = (q - a2n) & 2047;
+    uint64_t r = (uint64_t)p[e & 1023];
+    if (e & 1024) r = 0ull - r;
+    return r - (uint64_t)p[q];
+}
+THFHE_FN uint64_t decomp_offset64(int l, int Bgbit) {
+    uint64_t off = 0;
+    for (int p = 1; p <= l; p++) off += (1ull << (Bgbit - 1)) << (64 - p * Bgbit);
+    return off;
+}
+// top 32 bits of (X^a acc_j - acc_j)[lane + 64 m] + offset: every digit lives there because l*Bgbit <= 32
+THFHE_FN void load_rotated16_hi(int lane, const int64_t *acc_poly, int a2n, uint64_t offset, uint32_t (&t)[16]) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) t[m] = (uint32_t)((rot_minus_self64(acc_poly, lane + 64 * m, a2n) + offset) >> 32);
+}
+// four balanced 16-bit limbs of a Torus64 word: v = l0 + l1 2^16 + l2 2^32 + l3 2^48
+THFHE_FN void split_limbs64(int64_t v, double (&l)[4]) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        int64_t lo = (int64_t)(int16_t)(uint16_t)v;
+        l[q] = (double)lo;
+        v = (v - lo) >> 16;
+    }
+    l[3] = (double)v;
+}
+THFHE_FN void key_limbs64_to_z(int lane, const int64_t *poly, cplx (&z)[4][8]) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        double a[4], b[4];
+        split_limbs64(poly[lane + 64 * m], a);
+        split_limbs64(poly[lane + 64 * m + 512], b);
+#pragma unroll
+        for (int q = 0; q < 4; q++) z[q][m] = cplx{a[q], b[q]};
+    }
+}
+// round-to-nearest of x (|x| < 2^51) as int64
+THFHE_FN int64_t round_i64(double x) {
+    double y = x + 6755399441055744.0;
+    int64_t b;
+    __builtin_memcpy(&b, &y, 8);
+    return b - 0x4338000000000000ll;
+}
+// acc_poly[q] += sum_h round(limb_h) << 16h     for the 16 coefficients this lane owns
+THFHE_FN void acc_update16_64(int lane, int64_t *acc_poly, const cplx (&S)[4][8]) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        int q = lane + 64 * m;
+        uint64_t vr = 0, vi = 0;
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            vr += (uint64_t)round_i64(S[h][m].re) << (16 * h);
+            vi += (uint64_t)round_i64(S[h][m].im) << (16 * h);
+        }
+        acc_poly[q] = (int64_t)((uint64_t)acc_poly[q] + vr);
+        acc_poly[q + 512] = (int64_t)((uint64_t)acc_poly[q + 512] + vi);
+    }
+}
+THFHE_FN void acc_init16_64(int lane, int64_t *acc_mask, int64_t *acc_body, int barb, int64_t mu) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        int q = lane + 64 * m;
+        int e = (q + barb) & 2047;
+        acc_mask[q] = 0;
+        acc_body[q] = (e & 1024) ? (int64_t)(0ull - (uint64_t)mu) : mu;
+    }
+}
+// t64tot32 = trunc(Int32, Float64(d) / 2^32)                         J/numeric-functions.jl:109-111
+THFHE_FN int32_t t64tot32(int64_t d) {
+    double v = (double)d * (1.0 / 4294967296.0);
+    v = v < 0 ? -__builtin_floor(-v) : __builtin_floor(v);
+    return v >= 2147483648.0 ? INT32_MIN : (int32_t)v;
+}
+// rlwe_extract_sample_64                                             J/rlwe.jl:70-74
+THFHE_FN void extract16_64(int lane, const int64_t *acc_mask, const int64_t *acc_body, int32_t *out) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        int q = lane + 64 * m;
+        out[q] = t64tot32(q == 0 ? acc_mask[0] : (int64_t)(0ull - (uint64_t)acc_mask[1024 - q]));
+    }
+    if (lane == 0) out[1024] = t64tot32(acc_body[0]);
 }
 
 }  // namespace thfhe

@@ -1,31 +1,609 @@
-// thfhe_mk.hip -- 3-gen multi-key (Torus64 ring) path.  Placeholder: entry points exist so the ABI is complete,
-// and report THFHE_E_UNSUPPORTED until the Torus64 kernels land.
+// thfhe_mk.hip -- 3-gen multi-key (Torus64 ring) gate bootstrapping on gfx950: kernels + C ABI.
+//
+// Reference path: mk_gate_*_3gen (J/3gen_mk_gates.jl:8-150) -> mk_bootstrap_3gen (J/3gen_mk_internals.jl:112-116)
+//   = mk_bootstrap_wo_keyswitch_3gen (:99-109): P*n sequential CMuxes on ONE Torus64 accumulator, party-major
+//     (mk_blind_rotate_3gen :78-84, mk_mux_rotate_3gen :59-62, tgsw_extern_mul_3gen J/tgsw_3gen.jl:102-113),
+//     rlwe_extract_sample_64 (J/rlwe.jl:70-74)
+//   + mk_keyswitch_3gen (J/mk_internals.jl:730-744): one key switch per party, b = b' + sum of the parts' b.
+//
+// Kernels:
+//   mk_key_transform_kernel   TransformedBootstrapKeyPart_3gen (J/3gen_mk_internals.jl:45-56): int64 coefficient
+//                             polynomials -> four balanced 16-bit limbs -> FP64 spectra in streaming order
+//   mk_prologue_kernel        gate linear part + mod-switch of the (n, P) mask matrix and of b
+//   mk_blind_rotate_ring_kernel   one 512-thread workgroup = 4 gates x 2 waves (one wave per output polynomial
+//                             c1' / c0'), key streamed once per CU through the 3 x 8 KiB LDS ring (same machinery
+//                             as sk_blind_rotate_ring_kernel); all 160 KiB of LDS
+//   mk_keyswitch_kernel       P key switches of the extracted sample + the cross-party combine of b
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <new>
+#include <vector>
 
 #include "../../include/thfhe_hip.h"
 #include "thfhe_common.h"
+#include "thfhe_lane.h"
 
 using namespace thfhe;
 
-struct thfhe_mk_ctx {
-    thfhe_params p;
+namespace {
+
+__device__ __forceinline__ void mk_ring_dma(const cplx *gptr_lane, uint32_t lds_byte_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds_byte_off) : "memory", "m0");
+}
+template <int VM>
+__device__ __forceinline__ void mk_ring_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+}
+__device__ __forceinline__ void mk_fft_fwd(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
+    wave_sync();
+    fwds_seg1(lane, z, xb, T1);
+    wave_sync();
+    fwds_seg2_ld(lane, z, xb);
+    fwds_seg2_st(lane, z, xb, w);
+    wave_sync();
+    fwds_seg3(lane, z, xb);
+}
+__device__ __forceinline__ void mk_fft_inv(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
+    wave_sync();
+    invs_seg1(lane, z, xb, w);
+    wave_sync();
+    invs_seg2_ld(lane, z, xb);
+    invs_seg2_st(lane, z, xb);
+    wave_sync();
+    invs_seg3(lane, z, xb, T1);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// key transform: one wave per (pi, row, output) key polynomial, four limb spectra each
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mk_key_transform_kernel(const int64_t *__restrict__ bk, long PN, int l,
+                                                                const cplx *__restrict__ tw, cplx *__restrict__ spec) {
+    __shared__ cplx sT1[512];
+    __shared__ cplx sX[4][512];
+    for (int t = threadIdx.x; t < 512; t += 256) sT1[t] = tw[t];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const W64 w64{tw[512 + 1 * 8 + (lane & 7)], tw[512 + 2 * 8 + (lane & 7)], tw[512 + 4 * 8 + (lane & 7)]};
+    const int rows = 2 * l;
+    const long item = (long)blockIdx.x * 4 + wave;  // (pi, r, o)
+    if (item >= PN * rows * 2) return;
+    const int o = (int)(item & 1);
+    const int r = (int)((item >> 1) % rows);
+    const long pi = (item >> 1) / rows;
+    const int j = r / l, lv = r % l;
+    const int64_t *poly = bk + (((size_t)pi * 4 + mk_part_index(j, o)) * l + lv) * 1024;
+    cplx z[4][8];
+    key_limbs64_to_z(lane, poly, z);
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        mk_fft_fwd(lane, z[h], sX[wave], sT1, w64);
+        cplx *dst = spec + mk_chunk_index(pi, r, h, o, rows) * 512;
+#pragma unroll
+        for (int m = 0; m < 8; m++) dst[m * 64 + lane] = cplx{z[h][m].re * (1.0 / 512), z[h][m].im * (1.0 / 512)};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// prologue: tmp = (0, cb) + cx x + cy y + cz z ; bara[job][P*n], barb[job]
+// ------------------------------------------------------------------------------------------------------
+struct MKLin {
+    int32_t cb, cx, cy, cz;
+};
+inline bool mk_gate_lin(int op, int which, MKLin &L) {
+    const int32_t E8 = 1 << 29, E4 = 1 << 30;
+    switch (op) {
+    case THFHE_NAND: L = MKLin{E8, -1, -1, 0}; return true;   // J/3gen_mk_gates.jl:8-14
+    case THFHE_OR: L = MKLin{E8, 1, 1, 0}; return true;       // :24-30
+    case THFHE_AND: L = MKLin{-E8, 1, 1, 0}; return true;     // :40-46
+    case THFHE_XOR: L = MKLin{E4, 2, 2, 0}; return true;      // :68-74
+    case THFHE_AND3: L = MKLin{-E4, 1, 1, 1}; return true;    // :55-64
+    case THFHE_MUX: L = which == 0 ? MKLin{-E8, 1, 1, 0} : MKLin{-E8, -1, 0, 1}; return true;  // :133-150 (two ANDs)
+    case kOpIdentity: L = MKLin{0, 1, 0, 0}; return true;
+    default: return false;
+    }
+}
+__global__ __launch_bounds__(256) void mk_prologue_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ in1,
+                                                           const int32_t *__restrict__ in2, MKLin L0, MKLin L1, int rot_per_gate,
+                                                           int words, int w_pad, long jobs, int32_t *__restrict__ bara,
+                                                           int32_t *__restrict__ barb) {
+    const long job = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (job >= jobs || i > words) return;
+    const long gate = job / rot_per_gate;
+    const MKLin L = (job % rot_per_gate) == 0 ? L0 : L1;
+    const size_t off = (size_t)gate * (words + 1) + i;
+    uint32_t v = (uint32_t)L.cx * (uint32_t)in0[off];
+    if (L.cy != 0) v += (uint32_t)L.cy * (uint32_t)in1[off];
+    if (L.cz != 0) v += (uint32_t)L.cz * (uint32_t)in2[off];
+    if (i == words) {
+        v += (uint32_t)L.cb;
+        barb[job] = modswitch2n((int32_t)v, 11);
+    } else {
+        bara[job * w_pad + i] = modswitch2n((int32_t)v, 11);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// blind rotate + extract
+// ------------------------------------------------------------------------------------------------------
+struct MKBRArgs {
+    const cplx *bk;
+    const cplx *tw;
+    const int32_t *bara;  // [jobs][w_pad]
+    const int32_t *barb;
+    int32_t *out;         // [jobs][N+1]
+    long jobs;
+    int pn;               // parties * n : number of CMuxes
+    int w_pad, Bgbit;
+    int64_t mu;
 };
 
+template <int L>
+__global__ __launch_bounds__(512, 2) void mk_blind_rotate_ring_kernel(MKBRArgs a) {
+    __shared__ cplx sT1[512];
+    __shared__ int64_t sAcc[4][2048];
+    __shared__ cplx sX[8][512];
+    __shared__ cplx sRing[3][512];
+    constexpr int ROWS = 2 * L;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int g = wave & 3;   // gate within the workgroup
+    const int o = wave >> 2;  // output polynomial: 0 = c1' (mask), 1 = c0' (body); waves w and w+4 share a SIMD
+    sT1[threadIdx.x] = a.tw[threadIdx.x];
+    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)], a.tw[512 + 2 * 8 + (lane & 7)], a.tw[512 + 4 * 8 + (lane & 7)]};
+    const long job = (long)blockIdx.x * 4 + g;
+    const bool has_job = job < a.jobs;
+    int64_t *acc = sAcc[g];
+    cplx *xb = sX[wave];
+    const int32_t *bara = a.bara + (has_job ? job : 0) * a.w_pad;
+    const int Bgbit = a.Bgbit;
+    const uint64_t offset = decomp_offset64(L, Bgbit);
+    if (has_job && o == 0) acc_init16_64(lane, acc, acc + 1024, a.barb[job], a.mu);
+
+    const long total_chunks = (long)a.pn * ROWS * 8;
+    const cplx *gsrc = a.bk + wave * 64 + lane;
+    long q_issue = 0;
+    int slot_issue = 0;
+    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sRing[0][0] + (uint32_t)wave * 1024u;
+    auto issue = [&]() {
+        mk_ring_dma(gsrc, ring_base + (uint32_t)slot_issue * 8192u);
+        if (q_issue + 1 < total_chunks) {
+            gsrc += 512;
+            q_issue++;
+        }
+        slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
+    };
+    __syncthreads();
+    issue();
+    issue();
+    issue();
+    int slot_use = 0;
+
+    for (int i = 0; i < a.pn; i++) {  // party-major, key index inner: J/3gen_mk_internals.jl:66-84
+        const int ai = bara[i];
+        const bool active = has_job && ai != 0;
+        const int a2n = ai & 2047;
+        cplx S[4][8];
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+#pragma unroll
+            for (int m = 0; m < 8; m++) S[h][m] = cplx{0.0, 0.0};
+        uint32_t t[16];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            cplx z[8];
+            if (active) {
+                if (r % L == 0) load_rotated16_hi(lane, acc + (r / L) * 1024, a2n, offset, t);
+                digits_to_z(t, (r % L) + 1, Bgbit, z);
+                mk_fft_fwd(lane, z, xb, sT1, w64);
+            }
+#pragma unroll
+            for (int s = 0; s < 8; s++) {  // chunk (limb h = s >> 1, output s & 1)
+                if (s == 0) mk_ring_barrier<2>(); else mk_ring_barrier<1>();
+                if (s > 0) issue();
+                if (active && (s & 1) == o) mac8(lane, S[s >> 1], z, &sRing[slot_use][0]);
+                slot_use = slot_use == 2 ? 0 : slot_use + 1;
+            }
+            mk_ring_barrier<2>();
+            issue();
+        }
+        if (active) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) mk_fft_inv(lane, S[h], xb, sT1, w64);
+            acc_update16_64(lane, acc + o * 1024, S);
+        }
+        mk_ring_barrier<3>();  // both output waves have updated acc before anybody rotates it again
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (has_job && o == 0) extract16_64(lane, acc, acc + 1024, a.out + job * 1025);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// key switch: one workgroup per gate, parties in sequence          J/mk_internals.jl:730-744
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mk_ksk_pad_kernel(const int32_t *__restrict__ src, long rows, int n, int row_words,
+                                                          int32_t *__restrict__ dst) {
+    const long r = blockIdx.x;
+    if (r >= rows) return;
+    for (int q = threadIdx.x; q < row_words; q += 256) dst[r * row_words + q] = q <= n ? src[r * (n + 1) + q] : 0;
+}
+
+struct MKKSArgs {
+    const int32_t *ksk;  // [P][N][t][base-1][row_words]
+    const int32_t *u;    // [gates][N+1]
+    int32_t *out;        // [gates][P*n+1]
+    long gates;
+    int n, t, basebit, parties, row_words;
+};
+
+__global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a) {
+    __shared__ uint32_t sA[1024];
+    __shared__ uint32_t sRed[4][768];
+    __shared__ uint32_t sB;
+    const long g = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t prec_offset = 1u << (32 - (1 + a.basebit * a.t));
+    const int32_t *u = a.u + (size_t)g * 1025;
+    for (int q = tid; q < 1024; q += 256) sA[q] = (uint32_t)u[q] + prec_offset;
+    if (tid == 0) sB = (uint32_t)u[1024];
+    __syncthreads();
+    const int base1 = (1 << a.basebit) - 1;
+    const uint32_t mask = (uint32_t)base1;
+    const int wpl = a.row_words / 64;  // words per lane (<= 12)
+    int32_t *out = a.out + (size_t)g * ((size_t)a.parties * a.n + 1);
+    for (int p = 0; p < a.parties; p++) {
+        uint32_t r[12];
+#pragma unroll
+        for (int q = 0; q < 12; q++) r[q] = 0;
+        const int32_t *kp = a.ksk + (size_t)p * 1024 * a.t * base1 * a.row_words;
+        for (int i = wave; i < 1024; i += 4) {
+            const uint32_t ai = sA[i];
+            for (int j = 0; j < a.t; j++) {
+                const uint32_t d = (ai >> (32 - (j + 1) * a.basebit)) & mask;
+                if (d == 0) continue;
+                const int32_t *row = kp + (((size_t)i * a.t + j) * base1 + (d - 1)) * a.row_words + 2 * lane;
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if (2 * q < wpl) {
+                        const uint2 x = *reinterpret_cast<const uint2 *>(row + q * 128);
+                        r[2 * q] -= x.x;
+                        r[2 * q + 1] -= x.y;
+                    }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (2 * q < wpl) {
+                sRed[wave][q * 128 + 2 * lane] = r[2 * q];
+                sRed[wave][q * 128 + 2 * lane + 1] = r[2 * q + 1];
+            }
+        __syncthreads();
+        for (int q = tid; q <= a.n; q += 256) {
+            const uint32_t v = sRed[0][q] + sRed[1][q] + sRed[2][q] + sRed[3][q];
+            if (q < a.n) out[(size_t)p * a.n + q] = (int32_t)v;
+            else atomicAdd(&sB, v);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[(size_t)a.parties * a.n] = (int32_t)sB;
+}
+
+__global__ __launch_bounds__(256) void mk_linear_kernel(const int32_t *__restrict__ x, const int32_t *__restrict__ y, int32_t *__restrict__ out,
+                                                         size_t words, size_t rec, int mode) {
+    // mode 0: copy, 1: negate, 2: (0, 1/8) + x + y   (the 3-gen MUX epilogue, J/3gen_mk_gates.jl:144-147)
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= words) return;
+    uint32_t v = (uint32_t)x[q];
+    if (mode == 1) v = 0u - v;
+    if (mode == 2) {
+        v += (uint32_t)y[q];
+        if (q % rec == rec - 1) v += 1u << 29;
+    }
+    out[q] = (int32_t)v;
+}
+
+__global__ __launch_bounds__(256) void mk_mux_combine_kernel(const int32_t *__restrict__ t, int32_t *__restrict__ out, size_t words, size_t rec) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= words) return;
+    const size_t g = q / rec, w = q % rec;
+    uint32_t v = (uint32_t)t[(2 * g) * rec + w] + (uint32_t)t[(2 * g + 1) * rec + w];
+    if (w == rec - 1) v += 1u << 29;
+    out[q] = (int32_t)v;
+}
+
+}  // namespace
+
+struct thfhe_mk_ctx {
+    thfhe_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    cplx *d_bk = nullptr;
+    int32_t *d_ksk = nullptr;
+    cplx *d_tw = nullptr;
+    int row_words = 0, w_pad = 0, words = 0;
+    size_t cap_jobs = 0;
+    int32_t *d_bara = nullptr, *d_barb = nullptr, *d_u = nullptr, *d_tmp = nullptr;
+    size_t cap_stage = 0;
+    int32_t *d_in[3] = {nullptr, nullptr, nullptr};
+    int32_t *d_out = nullptr;
+    bool profiling = false, ev_valid = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::mutex mu;
+};
+
+namespace {
+
+int mk_ensure_workspace(thfhe_mk_ctx *c, size_t jobs) {
+    if (jobs <= c->cap_jobs) return THFHE_OK;
+    (void)hipFree(c->d_bara);
+    (void)hipFree(c->d_barb);
+    (void)hipFree(c->d_u);
+    (void)hipFree(c->d_tmp);
+    c->d_bara = c->d_barb = c->d_u = c->d_tmp = nullptr;
+    c->cap_jobs = 0;
+    THFHE_HIP(hipMalloc(&c->d_bara, jobs * c->w_pad * sizeof(int32_t)));
+    THFHE_HIP(hipMalloc(&c->d_barb, jobs * sizeof(int32_t)));
+    THFHE_HIP(hipMalloc(&c->d_u, jobs * 1025 * sizeof(int32_t)));
+    THFHE_HIP(hipMalloc(&c->d_tmp, jobs * (c->words + 1) * sizeof(int32_t)));
+    c->cap_jobs = jobs;
+    return THFHE_OK;
+}
+int mk_ensure_stage(thfhe_mk_ctx *c, size_t words) {
+    if (words <= c->cap_stage) return THFHE_OK;
+    for (auto &p : c->d_in) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    (void)hipFree(c->d_out);
+    c->d_out = nullptr;
+    c->cap_stage = 0;
+    for (auto &p : c->d_in) THFHE_HIP(hipMalloc(&p, words * sizeof(int32_t)));
+    THFHE_HIP(hipMalloc(&c->d_out, words * sizeof(int32_t)));
+    c->cap_stage = words;
+    return THFHE_OK;
+}
+
+// bootstrap (prologue + blind rotate + key switch) of `jobs` = gates * rot jobs; results to d_dst[jobs][P*n+1]
+int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1, const int32_t *d2, MKLin L0, MKLin L1, int rot,
+                          size_t gates, int64_t mu, int32_t *d_dst) {
+    const size_t jobs = gates * rot;
+    if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[0], c->stream));
+    dim3 pg((unsigned)((c->words + 1 + 255) / 256), (unsigned)jobs);
+    hipLaunchKernelGGL(mk_prologue_kernel, pg, dim3(256), 0, c->stream, d0, d1, d2, L0, L1, rot, c->words, c->w_pad, (long)jobs, c->d_bara, c->d_barb);
+    if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[1], c->stream));
+    MKBRArgs a{c->d_bk, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)jobs, c->p.parties * c->p.n, c->w_pad, c->p.Bgbit, mu};
+    const dim3 grid((unsigned)((jobs + 3) / 4)), block(512);
+    switch (c->p.l) {
+    case 1: hipLaunchKernelGGL(mk_blind_rotate_ring_kernel<1>, grid, block, 0, c->stream, a); break;
+    case 2: hipLaunchKernelGGL(mk_blind_rotate_ring_kernel<2>, grid, block, 0, c->stream, a); break;
+    case 3: hipLaunchKernelGGL(mk_blind_rotate_ring_kernel<3>, grid, block, 0, c->stream, a); break;
+    case 4: hipLaunchKernelGGL(mk_blind_rotate_ring_kernel<4>, grid, block, 0, c->stream, a); break;
+    default: return thfhe_fail(THFHE_E_UNSUPPORTED, "decomposition length l must be 1..4");
+    }
+    if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[2], c->stream));
+    MKKSArgs k{c->d_ksk, c->d_u, d_dst, (long)jobs, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words};
+    hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)jobs), dim3(256), 0, c->stream, k);
+    if (c->profiling) {
+        THFHE_HIP(hipEventRecord(c->ev[3], c->stream));
+        c->ev_valid = true;
+    }
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+
+int mk_gates_dev_locked(thfhe_mk_ctx *c, int op, const int32_t *d0, const int32_t *d1, const int32_t *d2, int32_t *dout, size_t count) {
+    if (count == 0) return THFHE_OK;
+    if (count > (size_t)INT32_MAX / 4) return thfhe_fail(THFHE_E_INVALID, "count too large");
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t rec = (size_t)c->words + 1, words = count * rec;
+    const unsigned lb = (unsigned)((words + 255) / 256);
+    if (op == THFHE_NOT || op == THFHE_COPY) {
+        hipLaunchKernelGGL(mk_linear_kernel, dim3(lb), dim3(256), 0, c->stream, d0, d0, dout, words, rec, op == THFHE_NOT ? 1 : 0);
+        THFHE_HIP(hipGetLastError());
+        return THFHE_OK;
+    }
+    MKLin L0, L1;
+    if (!mk_gate_lin(op, 0, L0) || op == kOpIdentity) return thfhe_fail(THFHE_E_INVALID, "gate not defined for the 3-gen multi-key scheme");
+    mk_gate_lin(op, 1, L1);
+    if (!d1 || ((op == THFHE_MUX || op == THFHE_AND3) && !d2)) return thfhe_fail(THFHE_E_INVALID, "null operand");
+    const int64_t MU = (int64_t)1 << 61;  // encode_message64(1, 8)
+    if (op != THFHE_MUX) {
+        int rc = mk_ensure_workspace(c, count);
+        if (rc) return rc;
+        return mk_enqueue_bootstraps(c, d0, d1, d2, L0, L0, 1, count, MU, dout);
+    }
+    // MUX: t1 = AND(x, y), t2 = AND(-x, z) as two full bootstraps, then (0, 1/8) + t1 + t2 without bootstrapping
+    int rc = mk_ensure_workspace(c, 2 * count);
+    if (rc) return rc;
+    rc = mk_enqueue_bootstraps(c, d0, d1, d2, L0, L1, 2, count, MU, c->d_tmp);  // job 2g: AND(x,y); job 2g+1: AND(-x,z)
+    if (rc) return rc;
+    // d_tmp holds [t1_0, t2_0, t1_1, t2_1, ...]: out = (0, 1/8) + t1 + t2            J/3gen_mk_gates.jl:144-147
+    hipLaunchKernelGGL(mk_mux_combine_kernel, dim3(lb), dim3(256), 0, c->stream, c->d_tmp, dout, words, rec);
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+
+}  // namespace
+
 extern "C" {
-int thfhe_mk_ctx_create(const thfhe_params *, const int64_t *, const int32_t *, int, thfhe_mk_ctx **out) {
-    if (out) *out = nullptr;
-    return thfhe_fail(THFHE_E_UNSUPPORTED, "multi-key (Torus64) path not implemented yet");
+
+int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const int32_t *ksk, int device, thfhe_mk_ctx **out) {
+    if (!p || !bk_coeff || !ksk || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    *out = nullptr;
+    if (p->torus_bits != 64) return thfhe_fail(THFHE_E_UNSUPPORTED, "thfhe_mk_ctx_create is the Torus64 3-gen multi-key path");
+    if (p->N != 1024 || p->k != 1) return thfhe_fail(THFHE_E_UNSUPPORTED, "only N = 1024, k = 1 is implemented");
+    if (p->parties < 1 || p->parties > 16) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= parties <= 16");
+    if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || p->Bgbit > 10 || p->l * p->Bgbit > 32)
+        return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 4, Bgbit <= 10 (FP64 exactness bound), l*Bgbit <= 32");
+    if (p->n < 1 || p->n > 767) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= n <= 767");
+    if (p->ks_t < 1 || p->ks_basebit < 1 || p->ks_t * p->ks_basebit > 31) return thfhe_fail(THFHE_E_INVALID, "bad key-switch parameters");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return thfhe_fail(THFHE_E_NO_DEVICE, "no usable HIP device (this library has no CPU fallback)");
+    THFHE_HIP(hipSetDevice(device));
+    thfhe_mk_ctx *c = new (std::nothrow) thfhe_mk_ctx;
+    if (!c) return thfhe_fail(THFHE_E_NOMEM, "out of host memory");
+    c->p = *p;
+    c->device = device;
+    c->words = p->parties * p->n;
+    c->w_pad = (c->words + 3) & ~3;
+    c->row_words = 128 * ((p->n + 1 + 127) / 128);
+    auto fail = [&](int code) {
+        thfhe_mk_ctx_destroy(c);
+        return code;
+    };
+#define CK(expr)                                                      \
+    do {                                                              \
+        hipError_t e_ = (expr);                                       \
+        if (e_ != hipSuccess) return fail(thfhe_fail_hip(e_, #expr)); \
+    } while (0)
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &e : c->ev) CK(hipEventCreate(&e));
+    std::vector<cplx> tw(576);
+    make_twiddles_1024(tw.data(), tw.data() + 512);
+    CK(hipMalloc(&c->d_tw, tw.size() * sizeof(cplx)));
+    CK(hipMemcpyAsync(c->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
+    const long PN = (long)p->parties * p->n;
+    const size_t coeff_words = (size_t)PN * 4 * p->l * 1024;
+    int64_t *d_coeff = nullptr;
+    CK(hipMalloc(&d_coeff, coeff_words * sizeof(int64_t)));
+    CK(hipMemcpyAsync(d_coeff, bk_coeff, coeff_words * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    const size_t chunks = (size_t)PN * 2 * p->l * 8;
+    CK(hipMalloc(&c->d_bk, chunks * 512 * sizeof(cplx)));
+    const long items = PN * 2 * p->l * 2;
+    hipLaunchKernelGGL(mk_key_transform_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, c->stream, d_coeff, PN, p->l, c->d_tw, c->d_bk);
+    CK(hipGetLastError());
+    const long rows = (long)p->parties * 1024 * p->ks_t * ((1 << p->ks_basebit) - 1);
+    int32_t *d_raw = nullptr;
+    CK(hipMalloc(&d_raw, (size_t)rows * (p->n + 1) * sizeof(int32_t)));
+    CK(hipMemcpyAsync(d_raw, ksk, (size_t)rows * (p->n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    CK(hipMalloc(&c->d_ksk, (size_t)rows * c->row_words * sizeof(int32_t)));
+    hipLaunchKernelGGL(mk_ksk_pad_kernel, dim3((unsigned)rows), dim3(256), 0, c->stream, d_raw, rows, p->n, c->row_words, c->d_ksk);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_coeff);
+    (void)hipFree(d_raw);
+#undef CK
+    *out = c;
+    return THFHE_OK;
 }
-void thfhe_mk_ctx_destroy(thfhe_mk_ctx *c) { delete c; }
-int thfhe_mk_gates(thfhe_mk_ctx *, int, const int32_t *, const int32_t *, const int32_t *, int32_t *, size_t) { return thfhe_fail(THFHE_E_UNSUPPORTED, "multi-key path not implemented yet"); }
-int thfhe_mk_bootstrap(thfhe_mk_ctx *, int64_t, const int32_t *, int32_t *, size_t) { return thfhe_fail(THFHE_E_UNSUPPORTED, "multi-key path not implemented yet"); }
-void *thfhe_mk_dev_alloc(thfhe_mk_ctx *, size_t) { return nullptr; }
-void thfhe_mk_dev_free(thfhe_mk_ctx *, void *) {}
-int thfhe_mk_copy_h2d(thfhe_mk_ctx *, void *, const void *, size_t) { return thfhe_fail(THFHE_E_UNSUPPORTED, "multi-key path not implemented yet"); }
-int thfhe_mk_copy_d2h(thfhe_mk_ctx *, void *, const void *, size_t) { return thfhe_fail(THFHE_E_UNSUPPORTED, "multi-key path not implemented yet"); }
-int thfhe_mk_reserve(thfhe_mk_ctx *, size_t) { return thfhe_fail(THFHE_E_UNSUPPORTED, "multi-key path not implemented yet"); }
-int thfhe_mk_gates_dev(thfhe_mk_ctx *, int, const int32_t *, const int32_t *, const int32_t *, int32_t *, size_t) { return thfhe_fail(THFHE_E_UNSUPPORTED, "multi-key path not implemented yet"); }
-int thfhe_mk_sync(thfhe_mk_ctx *) { return thfhe_fail(THFHE_E_UNSUPPORTED, "multi-key path not implemented yet"); }
-int thfhe_mk_set_profiling(thfhe_mk_ctx *, int) { return thfhe_fail(THFHE_E_UNSUPPORTED, "multi-key path not implemented yet"); }
-int thfhe_mk_last_timings(thfhe_mk_ctx *, float *) { return thfhe_fail(THFHE_E_UNSUPPORTED, "multi-key path not implemented yet"); }
+
+void thfhe_mk_ctx_destroy(thfhe_mk_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_bk);
+    (void)hipFree(c->d_ksk);
+    (void)hipFree(c->d_tw);
+    (void)hipFree(c->d_bara);
+    (void)hipFree(c->d_barb);
+    (void)hipFree(c->d_u);
+    (void)hipFree(c->d_tmp);
+    for (auto &p : c->d_in) (void)hipFree(p);
+    (void)hipFree(c->d_out);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
 }
+
+void *thfhe_mk_dev_alloc(thfhe_mk_ctx *c, size_t bytes) {
+    if (!c) return nullptr;
+    void *p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+void thfhe_mk_dev_free(thfhe_mk_ctx *c, void *p) {
+    if (c) (void)hipSetDevice(c->device);
+    (void)hipFree(p);
+}
+int thfhe_mk_copy_h2d(thfhe_mk_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    THFHE_HIP(hipSetDevice(c->device));
+    THFHE_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+int thfhe_mk_copy_d2h(thfhe_mk_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    THFHE_HIP(hipSetDevice(c->device));
+    THFHE_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+int thfhe_mk_reserve(thfhe_mk_ctx *c, size_t max_count) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    return mk_ensure_workspace(c, max_count * 2);
+}
+int thfhe_mk_sync(thfhe_mk_ctx *c) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+int thfhe_mk_set_profiling(thfhe_mk_ctx *c, int enabled) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    c->profiling = enabled != 0;
+    c->ev_valid = false;
+    return THFHE_OK;
+}
+int thfhe_mk_last_timings(thfhe_mk_ctx *c, float ms[4]) {
+    if (!c || !ms) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (!c->ev_valid) return thfhe_fail(THFHE_E_INVALID, "no profiled call recorded");
+    THFHE_HIP(hipEventSynchronize(c->ev[3]));
+    THFHE_HIP(hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));
+    THFHE_HIP(hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));
+    THFHE_HIP(hipEventElapsedTime(&ms[2], c->ev[2], c->ev[3]));
+    THFHE_HIP(hipEventElapsedTime(&ms[3], c->ev[0], c->ev[3]));
+    return THFHE_OK;
+}
+
+int thfhe_mk_gates_dev(thfhe_mk_ctx *c, int op, const int32_t *d0, const int32_t *d1, const int32_t *d2, int32_t *dout, size_t count) {
+    if (!c || !d0 || !dout) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    return mk_gates_dev_locked(c, op, d0, d1, d2, dout, count);
+}
+
+int thfhe_mk_gates(thfhe_mk_ctx *c, int op, const int32_t *in0, const int32_t *in1, const int32_t *in2, int32_t *out, size_t count) {
+    if (!c || !in0 || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t words = count * ((size_t)c->words + 1), bytes = words * sizeof(int32_t);
+    int rc = mk_ensure_stage(c, words);
+    if (rc) return rc;
+    const int32_t *src[3] = {in0, in1, in2};
+    for (int q = 0; q < 3; q++)
+        if (src[q]) THFHE_HIP(hipMemcpyAsync(c->d_in[q], src[q], bytes, hipMemcpyHostToDevice, c->stream));
+    rc = mk_gates_dev_locked(c, op, c->d_in[0], in1 ? c->d_in[1] : nullptr, in2 ? c->d_in[2] : nullptr, c->d_out, count);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+int thfhe_mk_bootstrap(thfhe_mk_ctx *c, int64_t mu, const int32_t *x, int32_t *out, size_t count) {
+    if (!c || !x || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t words = count * ((size_t)c->words + 1), bytes = words * sizeof(int32_t);
+    int rc = mk_ensure_stage(c, words);
+    if (rc) return rc;
+    rc = mk_ensure_workspace(c, count);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(c->d_in[0], x, bytes, hipMemcpyHostToDevice, c->stream));
+    MKLin L;
+    mk_gate_lin(kOpIdentity, 0, L);
+    rc = mk_enqueue_bootstraps(c, c->d_in[0], c->d_in[0], c->d_in[0], L, L, 1, count, mu, c->d_out);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+}  // extern "C"

@@ -269,3 +269,94 @@ def gate_constant(ck, value):
 def bootstrap(ck, mu, x): return ck.bootstrap(x, mu)                              # bootstrap.jl:98-101
 def bootstrap_wo_keyswitch(ck, mu, x): return ck.bootstrap_wo_keyswitch(x, mu)    # bootstrap.jl:75-88
 def keyswitch(ck, u): return ck.keyswitch(u)                                      # keyswitch.jl:45-80
+
+
+# ---- 3-gen multi-key -------------------------------------------------------------------------------------
+class MKCloudKey:
+    """Evaluation context of the 3rd-generation multi-key scheme: the parties' TransformedBootstrapKeyPart_3gen
+    (3gen_mk_internals.jl:45-56) and KeyswitchKey tables on one MI355X.
+
+    bk_coeff: int64[P][n][4][l][N] (part_1..part_4 of every TGswSample_3gen, coefficient domain);
+    ksk: int32[P][N][t][base-1][n+1].  Records are int32[P*n+1] = a[p*n+i], b (MKLweSample, mk_internals.jl:23-37).
+    """
+
+    def __init__(self, params, bk_coeff, ksk, device=0):
+        self.params = p = params
+        bk = np.ascontiguousarray(bk_coeff, np.int64)
+        ks = np.ascontiguousarray(ksk, np.int32)
+        if bk.size != p.parties * p.n * 4 * p.l * p.N:
+            raise ValueError("bk_coeff has the wrong size for these parameters")
+        if ks.size != p.parties * p.N * p.ks_t * ((1 << p.ks_basebit) - 1) * (p.n + 1):
+            raise ValueError("ksk has the wrong size for these parameters")
+        h = _vp()
+        _check(lib().thfhe_mk_ctx_create(C.byref(p), bk.ctypes.data_as(_i64p), _p32(ks), device, C.byref(h)))
+        self.h = h
+        self.words = p.parties * p.n + 1
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.thfhe_mk_ctx_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gates(self, op, x, y=None, z=None):
+        x = _rec(x, self.words)
+        y = _rec(y, self.words) if y is not None else None
+        z = _rec(z, self.words) if z is not None else None
+        out = np.empty_like(x)
+        _check(lib().thfhe_mk_gates(self.h, op, _p32(x), _p32(y), _p32(z), _p32(out), x.shape[0]))
+        return out
+
+    def bootstrap(self, x, mu=MU8_64):
+        x = _rec(x, self.words)
+        out = np.empty_like(x)
+        _check(lib().thfhe_mk_bootstrap(self.h, mu, _p32(x), _p32(out), x.shape[0]))
+        return out
+
+    def _alloc(self, n):
+        return lib().thfhe_mk_dev_alloc(self.h, n)
+
+    def _free(self, p):
+        lib().thfhe_mk_dev_free(self.h, p)
+
+    def _h2d(self, dptr, arr):
+        _check(lib().thfhe_mk_copy_h2d(self.h, dptr, arr.ctypes.data_as(_vp), arr.nbytes))
+
+    def _d2h(self, arr, dptr):
+        _check(lib().thfhe_mk_copy_d2h(self.h, arr.ctypes.data_as(_vp), dptr, arr.nbytes))
+
+    def device_records(self, count):
+        return DeviceBuffer(self, count * self.words * 4)
+
+    def reserve(self, max_count):
+        _check(lib().thfhe_mk_reserve(self.h, max_count))
+
+    def gates_dev(self, op, dx, dy, dz, dout, count):
+        _check(lib().thfhe_mk_gates_dev(self.h, op, dx.ptr, dy.ptr if dy else None, dz.ptr if dz else None, dout.ptr, count))
+
+    def sync(self):
+        _check(lib().thfhe_mk_sync(self.h))
+
+    def set_profiling(self, on):
+        _check(lib().thfhe_mk_set_profiling(self.h, int(bool(on))))
+
+    def last_timings(self):
+        ms = (C.c_float * 4)()
+        _check(lib().thfhe_mk_last_timings(self.h, ms))
+        return dict(prologue_ms=ms[0], blind_rotate_ms=ms[1], keyswitch_ms=ms[2], total_ms=ms[3])
+
+
+# the reference's 3-gen gate API (3gen_mk_gates.jl:8-150); `bk` is the MKCloudKey (it holds bk and ks together)
+def mk_gate_nand_3gen(bk, x, y): return bk.gates(NAND, x, y)
+def mk_gate_or_3gen(bk, x, y): return bk.gates(OR, x, y)
+def mk_gate_and_3gen(bk, x, y): return bk.gates(AND, x, y)
+def mk_gate_xor_3gen(bk, x, y): return bk.gates(XOR, x, y)
+def mk_gate_3and_3gen(bk, x, y, z): return bk.gates(AND3, x, y, z)
+def mk_gate_mux_3gen(bk, x, y, z): return bk.gates(MUX, x, y, z)
+def mk_gate_not_3gen(bk, x): return bk.gates(NOT, x)
+def mk_bootstrap_3gen(bk, mu, x): return bk.bootstrap(x, mu)   # 3gen_mk_internals.jl:112-116
