@@ -10,11 +10,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+def declared_symbols(only=None):
     names = set()
     inc = os.path.join(ROOT, "include")
     for fn in sorted(os.listdir(inc)):
-        if not fn.endswith(".h"):
+        if not fn.endswith(".h") or (only and fn != only):
             continue
         src = open(os.path.join(inc, fn)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
@@ -33,7 +33,8 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(decl) if not hasattr(L, n)]
     assert not missing, f"declared in include/*.h but not exported: {missing}"
     # the Python host layer binds exactly the thfhe_* symbols of thfhe_hip.h
-    assert set(thfhe.SIGNATURES) == {n for n in decl if n.startswith("thfhe_")}
+    assert {"bootsNAND", "bootsAND", "bootsOR", "bootsXOR", "bootsMUX", "bootsNOT"} <= decl   # the libtfhe names the reference calls
+    assert set(thfhe.SIGNATURES) == declared_symbols("thfhe_hip.h")
 
 
 def test_params_struct_layout():

@@ -1,0 +1,85 @@
+"""GPU parity tests of the 3-gen multi-key path (pytest -m gpu): C ABI vs the MK oracle, bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mk2gpu(O):
+    import thfhe
+    p = O.make_params("MK2")
+    s = O.SIGMAS["MK2"]
+    K = O.MKKeys(p, 0x5EED0001, s["bk"], s["ks"])
+    ck = thfhe.MKCloudKey(thfhe.make_params("MK2"), K.bk, K.ksk, device=0)
+    yield p, K, O.MKOracle(p, K.bk, K.ksk), ck
+    ck.close()
+
+
+def test_mk2_gates_bit_exact(O, mk2gpu):
+    # mk_gate_{nand,or,and,xor,3and,mux,not}_3gen, J/3gen_mk_gates.jl:8-150
+    import thfhe
+    p, K, orc, ck = mk2gpu
+    s = O.SIGMAS["MK2"]
+    a = np.array([0, 0, 1, 1, 1, 0]); b = np.array([0, 1, 0, 1, 1, 0]); c = np.array([1, 0, 1, 0, 1, 1])
+    ca, cb, cc = (K.encrypt_bits(v, s["lwe"], 400 + q) for q, v in enumerate((a, b, c)))
+    api = {O.NAND: (thfhe.mk_gate_nand_3gen, lambda x, y: ~(x & y)), O.OR: (thfhe.mk_gate_or_3gen, lambda x, y: x | y),
+           O.AND: (thfhe.mk_gate_and_3gen, lambda x, y: x & y), O.XOR: (thfhe.mk_gate_xor_3gen, lambda x, y: x ^ y)}
+    for op, (fn, truth) in api.items():
+        got = fn(ck, ca, cb)
+        assert np.array_equal(got, orc.gates(op, ca, cb)), f"gate {op}"
+        assert np.array_equal(K.decrypt_bits(got), truth(a.astype(bool), b.astype(bool)))
+    got = thfhe.mk_gate_3and_3gen(ck, ca, cb, cc)
+    assert np.array_equal(got, orc.gates(O.AND3, ca, cb, cc))
+    assert np.array_equal(K.decrypt_bits(got), (a & b & c).astype(bool))
+    got = thfhe.mk_gate_mux_3gen(ck, ca, cb, cc)
+    assert np.array_equal(got, orc.gates(O.MUX, ca, cb, cc))
+    assert np.array_equal(K.decrypt_bits(got), np.where(a == 1, b, c).astype(bool))
+    assert np.array_equal(thfhe.mk_gate_not_3gen(ck, ca), orc.gates(O.NOT, ca))
+    # mk_bootstrap_3gen(bk, ks, mu, x)  J/3gen_mk_internals.jl:112-116
+    x = ca[:2]
+    ref = np.stack([orc.keyswitch(orc.bootstrap_wo_keyswitch(r)) for r in x])
+    assert np.array_equal(thfhe.mk_bootstrap_3gen(ck, thfhe.MU8_64, x), ref)
+    # gates the 3-gen scheme does not define are refused
+    with pytest.raises(thfhe.ThfheError):
+        ck.gates(thfhe.XNOR, ca, cb)
+    assert ck.gates(thfhe.NAND, ca[:0], cb[:0]).shape == (0, p.n * p.parties + 1)
+
+
+def test_mk2_batch_1024_properties(O, mk2gpu):
+    # BASELINE.json configs[2]: 2-party gate bootstrap, 1024-gate batch, device-resident records
+    import thfhe
+    p, K, orc, ck = mk2gpu
+    s = O.SIGMAS["MK2"]
+    B = 1024
+    rng = np.random.default_rng(5)
+    a, b = rng.integers(0, 2, B), rng.integers(0, 2, B)
+    xa, xb = K.encrypt_bits(a, s["lwe"], 501), K.encrypt_bits(b, s["lwe"], 502)
+    da, db, do = ck.device_records(B), ck.device_records(B), ck.device_records(B)
+    da.upload(xa); db.upload(xb); ck.reserve(B)
+    ck.gates_dev(thfhe.NAND, da, db, None, do, B); ck.sync()
+    out1 = do.download((B, p.n * p.parties + 1))
+    ck.gates_dev(thfhe.NAND, da, db, None, do, B); ck.sync()
+    assert np.array_equal(out1, do.download((B, p.n * p.parties + 1)))          # deterministic
+    assert np.array_equal(K.decrypt_bits(out1), ~(a.astype(bool) & b.astype(bool)))
+    assert np.abs(np.abs(K.phases(out1) / 2.0**32) - 0.125).max() < 0.125
+    idx = rng.choice(B, 8, replace=False)
+    assert np.array_equal(out1[idx], orc.gates(O.NAND, xa[idx], xb[idx]))
+    # odd batch size (not a multiple of the 4 gates a workgroup holds)
+    assert np.array_equal(ck.gates(thfhe.XOR, xa[:5], xb[:5]), orc.gates(O.XOR, xa[:5], xb[:5]))
+
+
+def test_mk4_bit_exact(O):
+    # mktfhe_parameters_4party_3gen: P = 4, n = 510, l = 3, Bgbit = 6, ks 5/2    (J/mk_api.jl:84-90)
+    import thfhe
+    p = O.make_params("MK4")
+    s = O.SIGMAS["MK4"]
+    K = O.MKKeys(p, 77, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    ck = thfhe.MKCloudKey(thfhe.make_params("MK4"), K.bk, K.ksk, device=0)
+    a = np.array([0, 1, 1, 0]); b = np.array([1, 1, 0, 0])
+    ca, cb = K.encrypt_bits(a, s["lwe"], 1), K.encrypt_bits(b, s["lwe"], 2)
+    got = ck.gates(thfhe.NAND, ca, cb)
+    assert np.array_equal(got, orc.gates(O.NAND, ca, cb))
+    assert np.array_equal(K.decrypt_bits(got), ~(a.astype(bool) & b.astype(bool)))
+    ck.close()

@@ -91,6 +91,41 @@ def test_cmux_and_blind_rotate_bit_exact(E, O, sk_small):
     assert np.array_equal(ref, out)
 
 
+def test_swizzled_variant_matches_padded(E, O):
+    # the LDS-ring kernel's unpadded / XOR-swizzled buffer and power-twiddles give the same spectra and exact products
+    E.emu_variant_crosscheck.restype = C.c_double
+    rng = np.random.default_rng(8)
+    a = rng.integers(-512, 512, 1024).astype(np.int32); b = rng.integers(-2**31, 2**31, 1024).astype(np.int32)
+    ref, got = np.zeros(1024, np.int32), np.zeros(1024, np.int32)
+    O.lib().oracle_polymul_schoolbook32(O.p32(a), O.p32(b), 1024, O.p32(ref))
+    d = E.emu_variant_crosscheck(O.p32(a), O.p32(b), O.p32(got))
+    assert np.array_equal(ref, got) and d < 1e-9
+
+
+def test_mk_cmux_and_extract_bit_exact(E, O):
+    # Torus64 3-gen CMux through the lane code (four 16-bit limbs, hi-word digits) vs the MK oracle's schoolbook path
+    for name, n, parties in (("MK2", 6, 2), ("MK4", 3, 2)):
+        p = O.make_params(name, n=n, parties=parties)
+        K = O.MKKeys(p, 3, 2.0**-30.70, 2.0**-13.52)
+        orc = O.MKOracle(p, K.bk, K.ksk)
+        PN = p.parties * p.n
+        spec = np.zeros(PN * 2 * p.l * 8 * 512 * 2, np.float64)
+        E.emu_mk_transform_key(O.p64(K.bk), C.c_long(PN), p.l, dptr(spec))
+        acc = np.random.default_rng(5).integers(-2**63, 2**63, (2, 1024)).astype(np.int64)
+        for party, i, a in [(0, 0, 5), (1, n - 1, -1000), (0, 1, 1023), (1, 2, -1024)]:
+            ref = orc.mux_rotate(party, i, a, acc, schoolbook=True)
+            got = acc.copy()
+            E.emu_mk_mux_rotate(dptr(spec), p.l, p.Bgbit, C.c_long(party * p.n + i), a, O.p64(got))
+            assert np.array_equal(ref, got)
+            acc = ref
+        acc[0, 5] = -2**63
+        out = np.zeros(1025, np.int32)
+        E.emu_mk_extract(O.p64(acc), O.p32(out))
+        f = O.lib().oracle_t64tot32
+        exp = [f(int(acc[0, 0]))] + [f(int(((-int(acc[0, 1024 - q])) + 2**63) % 2**64 - 2**63)) for q in range(1, 1024)] + [f(int(acc[1, 0]))]
+        assert np.array_equal(out, np.array(exp, np.int32))
+
+
 def test_cmux_l2_bgbit10(E, O):
     # the SK-80 shape (l = 2, Bgbit = 10) exercises the largest digits the Torus32 engine accepts
     p = O.make_params("SK-80", n=4)

@@ -1,0 +1,161 @@
+// tfhe_shim.cpp -- the libtfhe gate symbols (include/tfhe_shim.h) on top of the batch C ABI.
+#include "../../include/tfhe_shim.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstddef>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/thfhe_hip.h"
+
+static_assert(sizeof(LweParams) == 24 && offsetof(LweParams, alpha_min) == 8, "LweParams layout");
+static_assert(sizeof(LweSample) == 24 && offsetof(LweSample, b) == 8 && offsetof(LweSample, current_variance) == 16, "LweSample layout");
+static_assert(offsetof(LweKeySwitchKey, out_params) == 16 && offsetof(LweKeySwitchKey, ks) == 40, "LweKeySwitchKey layout");
+static_assert(sizeof(TLweParams) == 48 && offsetof(TLweParams, extracted_lweparams) == 24, "TLweParams layout");
+static_assert(offsetof(TorusPolynomial, coefsT) == 8, "TorusPolynomial layout");
+static_assert(offsetof(TLweSample, b) == 8 && offsetof(TLweSample, k) == 24, "TLweSample layout");
+static_assert(offsetof(TGswParams, maskMod) == 16 && offsetof(TGswParams, tlwe_params) == 24 && offsetof(TGswParams, kpl) == 32 &&
+                  offsetof(TGswParams, h) == 40 && offsetof(TGswParams, offset) == 48, "TGswParams layout");
+static_assert(offsetof(TGswSample, k) == 16 && offsetof(TGswSample, l) == 20, "TGswSample layout");
+static_assert(offsetof(LweBootstrappingKey, bk) == 32 && offsetof(LweBootstrappingKey, ks) == 40, "LweBootstrappingKey layout");
+static_assert(offsetof(TFheGateBootstrappingParameterSet, in_out_params) == 8 && offsetof(TFheGateBootstrappingParameterSet, tgsw_params) == 16, "ParameterSet layout");
+static_assert(offsetof(TFheGateBootstrappingCloudKeySet, bk) == 8 && offsetof(TFheGateBootstrappingCloudKeySet, bkFFT) == 16, "CloudKeySet layout");
+
+namespace {
+
+struct Entry {
+    thfhe_ctx *ctx;
+    int n;
+};
+std::mutex g_mu;
+std::map<const TFheGateBootstrappingCloudKeySet *, Entry> g_ctx;
+
+[[noreturn]] void die(const char *what) {
+    // the libtfhe gate functions return void and abort on internal errors ("Errors")
+    std::fprintf(stderr, "libthfhe_hip (tfhe shim): %s: %s\n", what, thfhe_last_error());
+    std::abort();
+}
+
+Entry get_ctx(const TFheGateBootstrappingCloudKeySet *bk) {
+    std::lock_guard<std::mutex> g(g_mu);
+    auto it = g_ctx.find(bk);
+    if (it != g_ctx.end()) return it->second;
+    const LweBootstrappingKey *b = bk->bk;
+    thfhe_params p{};
+    p.n = b->in_out_params->n;
+    p.N = b->accum_params->N;
+    p.k = b->accum_params->k;
+    p.l = b->bk_params->l;
+    p.Bgbit = b->bk_params->Bgbit;
+    p.ks_t = b->ks->t;
+    p.ks_basebit = b->ks->basebit;
+    p.torus_bits = 32;
+    p.parties = 1;
+    const int rows = (p.k + 1) * p.l, N = p.N;
+    std::vector<int32_t> bkc((size_t)p.n * rows * (p.k + 1) * N);
+    for (int i = 0; i < p.n; i++)
+        for (int r = 0; r < rows; r++)
+            for (int c = 0; c <= p.k; c++) {
+                const Torus32 *src = b->bk[i].all_sample[r].a[c].coefsT;
+                int32_t *dst = bkc.data() + (((size_t)i * rows + r) * (p.k + 1) + c) * N;
+                for (int q = 0; q < N; q++) dst[q] = src[q];
+            }
+    const int base = 1 << p.ks_basebit, Nin = b->ks->n;
+    std::vector<int32_t> ksk((size_t)Nin * p.ks_t * (base - 1) * (p.n + 1));
+    for (int i = 0; i < Nin; i++)
+        for (int j = 0; j < p.ks_t; j++)
+            for (int h = 1; h < base; h++) {
+                const LweSample *s = &b->ks->ks[i][j][h];
+                int32_t *dst = ksk.data() + ((((size_t)i * p.ks_t + j) * (base - 1)) + (h - 1)) * (p.n + 1);
+                for (int q = 0; q < p.n; q++) dst[q] = s->a[q];
+                dst[p.n] = s->b;
+            }
+    Entry e{nullptr, p.n};
+    const char *dev = std::getenv("THFHE_DEVICE");
+    if (thfhe_ctx_create(&p, bkc.data(), ksk.data(), dev ? std::atoi(dev) : 0, &e.ctx) != THFHE_OK) die("cannot create device context");
+    g_ctx[bk] = e;
+    return e;
+}
+
+void run(int op, LweSample *result, const LweSample *ca, const LweSample *cb, const LweSample *cc, int count,
+         const TFheGateBootstrappingCloudKeySet *bk) {
+    const Entry e = get_ctx(bk);
+    const size_t rec = (size_t)e.n + 1;
+    std::vector<int32_t> buf(4 * rec * count);
+    int32_t *x = buf.data(), *y = x + rec * count, *z = y + rec * count, *o = z + rec * count;
+    auto pack = [&](int32_t *dst, const LweSample *s) {
+        for (int g = 0; g < count; g++) {
+            for (int q = 0; q < e.n; q++) dst[g * rec + q] = s[g].a[q];
+            dst[g * rec + e.n] = s[g].b;
+        }
+    };
+    pack(x, ca);
+    if (cb) pack(y, cb);
+    if (cc) pack(z, cc);
+    if (thfhe_gates(e.ctx, op, x, cb ? y : nullptr, cc ? z : nullptr, o, (size_t)count) != THFHE_OK) die("gate evaluation failed");
+    for (int g = 0; g < count; g++) {  // inputs were fully read above: result may alias them
+        for (int q = 0; q < e.n; q++) result[g].a[q] = o[g * rec + q];
+        result[g].b = o[g * rec + e.n];
+        result[g].current_variance = 0.0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+#define THFHE_GATE2(NAME, OP)                                                                                                   \
+    void NAME(LweSample *result, const LweSample *ca, const LweSample *cb, const TFheGateBootstrappingCloudKeySet *bk) {        \
+        run(OP, result, ca, cb, nullptr, 1, bk);                                                                                \
+    }
+THFHE_GATE2(bootsNAND, THFHE_NAND)
+THFHE_GATE2(bootsOR, THFHE_OR)
+THFHE_GATE2(bootsAND, THFHE_AND)
+THFHE_GATE2(bootsXOR, THFHE_XOR)
+THFHE_GATE2(bootsXNOR, THFHE_XNOR)
+THFHE_GATE2(bootsNOR, THFHE_NOR)
+THFHE_GATE2(bootsANDNY, THFHE_ANDNY)
+THFHE_GATE2(bootsANDYN, THFHE_ANDYN)
+THFHE_GATE2(bootsORNY, THFHE_ORNY)
+THFHE_GATE2(bootsORYN, THFHE_ORYN)
+#undef THFHE_GATE2
+
+void bootsMUX(LweSample *result, const LweSample *a, const LweSample *b, const LweSample *c, const TFheGateBootstrappingCloudKeySet *bk) {
+    run(THFHE_MUX, result, a, b, c, 1, bk);
+}
+void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
+    const int n = bk->params->in_out_params->n;  // not bootstrapped: plain negation (J/gates.jl:76-79)
+    for (int q = 0; q < n; q++) result->a[q] = (Torus32)(0u - (uint32_t)ca->a[q]);
+    result->b = (Torus32)(0u - (uint32_t)ca->b);
+    result->current_variance = ca->current_variance;
+}
+void bootsCOPY(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
+    const int n = bk->params->in_out_params->n;
+    for (int q = 0; q < n; q++) result->a[q] = ca->a[q];
+    result->b = ca->b;
+    result->current_variance = ca->current_variance;
+}
+void bootsCONSTANT(LweSample *result, int32_t value, const TFheGateBootstrappingCloudKeySet *bk) {
+    const int n = bk->params->in_out_params->n;  // noiseless trivial +-1/8 (J/gates.jl:91-93)
+    for (int q = 0; q < n; q++) result->a[q] = 0;
+    result->b = value ? (1 << 29) : -(1 << 29);
+    result->current_variance = 0.0;
+}
+int thfhe_tfhe_gate_batch(int op, LweSample *result, const LweSample *ca, const LweSample *cb, const LweSample *cc, int32_t count,
+                          const TFheGateBootstrappingCloudKeySet *bk) {
+    if (!result || !ca || !bk || count < 0) return THFHE_E_INVALID;
+    if (count == 0) return THFHE_OK;
+    run(op, result, ca, cb, cc, count, bk);
+    return THFHE_OK;
+}
+void thfhe_tfhe_forget_key(const TFheGateBootstrappingCloudKeySet *bk) {
+    std::lock_guard<std::mutex> g(g_mu);
+    auto it = g_ctx.find(bk);
+    if (it != g_ctx.end()) {
+        thfhe_ctx_destroy(it->second.ctx);
+        g_ctx.erase(it);
+    }
+}
+}

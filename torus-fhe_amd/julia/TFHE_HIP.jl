@@ -1,0 +1,131 @@
+# TFHE_HIP.jl -- thin Julia host layer over libthfhe_hip.so (include/thfhe_hip.h).
+#
+# Keeps the reference's names and argument order for the bootstrapped-gate path (3-gen-mk-tfhe/src/gates.jl,
+# bootstrap.jl, keyswitch.jl, 3gen_mk_gates.jl, 3gen_mk_internals.jl) so that `using .TFHE_HIP` next to the reference's
+# `TFHE` module swaps ONLY that path: keys and ciphertexts are still produced by the reference's own keygen/encrypt, then
+# handed over as flat arrays.  Julia is not installed in the build container, so this file is NOT exercised by the test
+# suite; the identical call sequence is tested through the Python ctypes layer (torus-fhe_amd/thfhe/__init__.py).
+module TFHE_HIP
+
+export HipCloudKey, HipMKCloudKey, gate_nand, gate_or, gate_and, gate_xor, gate_xnor, gate_nor, gate_andny, gate_andyn,
+       gate_orny, gate_oryn, gate_mux, gate_not, bootstrap, bootstrap_wo_keyswitch, keyswitch,
+       mk_gate_nand_3gen, mk_gate_or_3gen, mk_gate_and_3gen, mk_gate_xor_3gen, mk_gate_3and_3gen, mk_gate_mux_3gen,
+       mk_gate_not_3gen, mk_bootstrap_3gen
+
+const LIB = get(ENV, "THFHE_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libthfhe_hip.so"))
+
+struct Params                      # thfhe_params
+    n::Int32; N::Int32; k::Int32; l::Int32; Bgbit::Int32; ks_t::Int32; ks_basebit::Int32; torus_bits::Int32; parties::Int32
+end
+
+const NAND, OR, AND, XOR, XNOR, NOR, ANDNY, ANDYN, ORNY, ORYN, MUX, NOT, COPY, AND3 = Int32.(0:13)
+
+lasterror() = unsafe_string(ccall((:thfhe_last_error, LIB), Cstring, ()))
+check(rc) = rc == 0 ? nothing : error("libthfhe_hip error $rc: $(lasterror())")
+
+# ---- single key -------------------------------------------------------------------------------------------
+mutable struct HipCloudKey
+    h::Ptr{Cvoid}
+    params::Params
+end
+
+"""
+    HipCloudKey(params, bk_coeff, ksk; device=0)
+
+`bk_coeff :: Array{Int32}` with memory order [N][k+1][(k+1)l][n] column-major (= C order [n][(k+1)l][k+1][N]):
+the coefficient-domain TGSW rows of `BootstrapKey` BEFORE `forward_transform` (bootstrap.jl:11); row index j*l + p.
+`ksk :: Array{Int32}` in C order [N][t][base-1][n+1] (`KeyswitchKey.key[h, j, i]` -> a..., b).
+"""
+function HipCloudKey(p::Params, bk_coeff::Array{Int32}, ksk::Array{Int32}; device::Integer=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:thfhe_ctx_create, LIB), Cint, (Ref{Params}, Ptr{Int32}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}), p, bk_coeff, ksk, device, h))
+    ck = HipCloudKey(h[], p)
+    finalizer(c -> ccall((:thfhe_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.h), ck)
+    ck
+end
+
+# LWE samples travel as Int32 matrices of size (n+1, count): column g = (a..., b) of gate g
+function gates(ck::HipCloudKey, op::Int32, x::Matrix{Int32}, y=nothing, z=nothing)
+    out = similar(x)
+    yp = y === nothing ? Ptr{Int32}(C_NULL) : pointer(y)
+    zp = z === nothing ? Ptr{Int32}(C_NULL) : pointer(z)
+    GC.@preserve x y z out check(ccall((:thfhe_gates, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Csize_t), ck.h, op, x, yp, zp, out, size(x, 2)))
+    out
+end
+
+gate_nand(ck::HipCloudKey, x, y) = gates(ck, NAND, x, y)          # gates.jl:15-18
+gate_or(ck::HipCloudKey, x, y) = gates(ck, OR, x, y)              # :27-30
+gate_and(ck::HipCloudKey, x, y) = gates(ck, AND, x, y)            # :39-42
+gate_xor(ck::HipCloudKey, x, y) = gates(ck, XOR, x, y)            # :51-54
+gate_xnor(ck::HipCloudKey, x, y) = gates(ck, XNOR, x, y)          # :63-66
+gate_nor(ck::HipCloudKey, x, y) = gates(ck, NOR, x, y)            # :103-106
+gate_andny(ck::HipCloudKey, x, y) = gates(ck, ANDNY, x, y)        # :115-118
+gate_andyn(ck::HipCloudKey, x, y) = gates(ck, ANDYN, x, y)        # :127-130
+gate_orny(ck::HipCloudKey, x, y) = gates(ck, ORNY, x, y)          # :139-142
+gate_oryn(ck::HipCloudKey, x, y) = gates(ck, ORYN, x, y)          # :151-154
+gate_mux(ck::HipCloudKey, x, y, z) = gates(ck, MUX, x, y, z)      # :163-177
+gate_not(ck::HipCloudKey, x) = gates(ck, NOT, x)                  # :76-79
+
+function bootstrap(ck::HipCloudKey, mu::Int32, x::Matrix{Int32})                       # bootstrap.jl:98-101
+    out = similar(x)
+    check(ccall((:thfhe_bootstrap, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}, Csize_t), ck.h, mu, x, out, size(x, 2)))
+    out
+end
+function bootstrap_wo_keyswitch(ck::HipCloudKey, mu::Int32, x::Matrix{Int32})          # bootstrap.jl:75-88
+    out = Matrix{Int32}(undef, ck.params.N + 1, size(x, 2))
+    check(ccall((:thfhe_bootstrap_wo_keyswitch, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}, Csize_t), ck.h, mu, x, out, size(x, 2)))
+    out
+end
+function keyswitch(ck::HipCloudKey, u::Matrix{Int32})                                  # keyswitch.jl:45-80
+    out = Matrix{Int32}(undef, ck.params.n + 1, size(u, 2))
+    check(ccall((:thfhe_keyswitch, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Csize_t), ck.h, u, out, size(u, 2)))
+    out
+end
+
+# ---- 3-gen multi-key ------------------------------------------------------------------------------------------
+mutable struct HipMKCloudKey
+    h::Ptr{Cvoid}
+    params::Params
+end
+
+"""
+    HipMKCloudKey(params, bk_coeff, ksk; device=0)
+
+`bk_coeff :: Array{Int64}` in C order [P][n][4][l][N]: part_1..part_4 of every `TGswSample_3gen` of every party's
+`BootstrapKeyPart_3gen.gsw_key` (coefficient domain, i.e. before `TransformedBootstrapKeyPart_3gen`);
+`ksk :: Array{Int32}` in C order [P][N][t][base-1][n+1].  MK samples are Int32 matrices (P*n+1, count): a[:,p] stacked, then b.
+"""
+function HipMKCloudKey(p::Params, bk_coeff::Array{Int64}, ksk::Array{Int32}; device::Integer=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:thfhe_mk_ctx_create, LIB), Cint, (Ref{Params}, Ptr{Int64}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}), p, bk_coeff, ksk, device, h))
+    ck = HipMKCloudKey(h[], p)
+    finalizer(c -> ccall((:thfhe_mk_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.h), ck)
+    ck
+end
+
+function mk_gates(ck::HipMKCloudKey, op::Int32, x::Matrix{Int32}, y=nothing, z=nothing)
+    out = similar(x)
+    yp = y === nothing ? Ptr{Int32}(C_NULL) : pointer(y)
+    zp = z === nothing ? Ptr{Int32}(C_NULL) : pointer(z)
+    GC.@preserve x y z out check(ccall((:thfhe_mk_gates, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Csize_t), ck.h, op, x, yp, zp, out, size(x, 2)))
+    out
+end
+
+# the reference passes (bk, ks, x, y); here the context holds both key tables        3gen_mk_gates.jl:8-150
+mk_gate_nand_3gen(ck::HipMKCloudKey, x, y) = mk_gates(ck, NAND, x, y)
+mk_gate_or_3gen(ck::HipMKCloudKey, x, y) = mk_gates(ck, OR, x, y)
+mk_gate_and_3gen(ck::HipMKCloudKey, x, y) = mk_gates(ck, AND, x, y)
+mk_gate_xor_3gen(ck::HipMKCloudKey, x, y) = mk_gates(ck, XOR, x, y)
+mk_gate_3and_3gen(ck::HipMKCloudKey, x, y, z) = mk_gates(ck, AND3, x, y, z)
+mk_gate_mux_3gen(ck::HipMKCloudKey, x, y, z) = mk_gates(ck, MUX, x, y, z)
+mk_gate_not_3gen(ck::HipMKCloudKey, x) = mk_gates(ck, NOT, x)
+
+function mk_bootstrap_3gen(ck::HipMKCloudKey, mu::Int64, x::Matrix{Int32})              # 3gen_mk_internals.jl:112-116
+    out = similar(x)
+    check(ccall((:thfhe_mk_bootstrap, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Csize_t), ck.h, mu, x, out, size(x, 2)))
+    out
+end
+
+end # module
