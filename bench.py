@@ -190,6 +190,11 @@ def main():
                                     "frac": value / world * ab["total"] / 1e9 / HBM_PEAK_GBS}},
         "bit_exact_decrypt_errors": errors,
     }
+    tfile = os.path.join(ROOT, "profiles", "traffic_sk128.json")
+    if not mk and args.set == "SK-128" and B == 4096 and os.path.exists(tfile):
+        # HBM bytes per blind-rotate launch from the committed PMC passes of this same workload (bench.py cannot run rocprofv3 on itself)
+        res["roofline"]["traffic"] = json.load(open(tfile))["traffic_bytes_per_launch"]
+        res["roofline"]["traffic_source"] = "profiles/traffic_sk128.json"
     if world == 1 and not args.no_cpu_baseline and not mk:
         threads = len(os.sched_getaffinity(0))
         sample = args.cpu_sample or max(8, 8 * min(threads, 64))
