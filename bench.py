@@ -51,6 +51,10 @@ def dist_setup(n_gpus):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     backend = os.environ.get("THFHE_BENCH_BACKEND", "nccl")
     dev = None
+    # RCCL / gloo print start-up banners on the C-level stdout: keep stdout clean for the single JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if backend == "nccl":
         try:
             torch.cuda.set_device(local)
@@ -67,6 +71,10 @@ def dist_setup(n_gpus):
     if backend == "gloo":
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dev = torch.device("cpu")
+        dist.barrier()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
 
     def barrier():
         if dev.type == "cuda":
