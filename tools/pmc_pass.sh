@@ -4,7 +4,7 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$TAG -- python3 $R/tools/ablate.py 4096 > $OUT/pmc_$TAG.log 2>&1
+rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$TAG -- python3 $R/tools/time_batch.py 4096 > $OUT/pmc_$TAG.log 2>&1
 python3 - $OUT/pmc_$TAG <<'PY'
 import csv,glob,sys
 from collections import defaultdict

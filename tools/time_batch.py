@@ -1,0 +1,20 @@
+"""Developer timing: one NAND batch of a given size (env THFHE_BR_VARIANT=1 selects the first-generation kernel)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "torus-fhe_amd"))
+import thfhe
+from thfhe import keygen
+p = thfhe.make_params("SK-128")
+K = keygen.SecretKeySet(p, seed=1)
+ck = thfhe.CloudKey(p, K.bk, K.ksk)
+for B in [int(x) for x in sys.argv[1:]] or [4096]:
+    rng = np.random.default_rng(0)
+    xa, xb = K.encrypt(rng.integers(0, 2, B), 1), K.encrypt(rng.integers(0, 2, B), 2)
+    da, db, do = ck.device_records(B), ck.device_records(B), ck.device_records(B)
+    da.upload(xa); db.upload(xb); ck.reserve(B); ck.set_profiling(True)
+    for rep in range(3):
+        ck.gates_dev(thfhe.NAND, da, db, None, do, B); ck.sync()
+        t = ck.last_timings()
+    print(f"variant={os.environ.get('THFHE_BR_VARIANT','3')} batch {B}: blind_rotate {t['blind_rotate_ms']:.3f} ms keyswitch {t['keyswitch_ms']:.3f} ms total {t['total_ms']:.3f} ms -> {B/t['total_ms']*1e3:.0f} gates/s", flush=True)
+    for d in (da, db, do): d.free()

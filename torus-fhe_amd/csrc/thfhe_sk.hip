@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void sk_prologue_kernel(const int32_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------------
-// blind rotate + extract.  4 waves per workgroup, each wave one job; 78 848 B LDS -> 2 workgroups per CU.
+// blind rotate + extract, first generation (kept for A/B: THFHE_BR_VARIANT=1).  4 waves per workgroup, each wave one job
+// with its own key loads; 78 848 B LDS -> 2 workgroups per CU.  Bound by the CU's vector-memory path (profiles/r01_summary.md).
 // ------------------------------------------------------------------------------------------------------
 struct BRArgs {
     const cplx *bk;        // spectral key
@@ -114,7 +115,7 @@ struct BRArgs {
     int32_t mu;
 };
 
-template <int L, int ABL>
+template <int L>
 __global__ __launch_bounds__(256, 2) void sk_blind_rotate_kernel(BRArgs a) {
     __shared__ cplx sT1[512];
     __shared__ cplx sT2[64];
@@ -157,23 +158,11 @@ __global__ __launch_bounds__(256, 2) void sk_blind_rotate_kernel(BRArgs a) {
                 cplx z[8];
                 digits_to_z(t, p, Bgbit, z);
                 wave_fft_fwd(lane, z, xb, sT1, sT2);
-                if (ABL == 2) {  // ablation: no key traffic at all (results meaningless)
-#pragma unroll
-                    for (int c = 0; c < 2; c++)
-#pragma unroll
-                        for (int h = 0; h < 2; h++)
-#pragma unroll
-                            for (int m = 0; m < 8; m++) {
-                                S[c][h][m].re += z[m].re * z[(m + c) & 7].re - z[m].im * z[(m + h) & 7].im;
-                                S[c][h][m].im += z[m].re * z[(m + h) & 7].im + z[m].im * z[(m + c) & 7].re;
-                            }
-                } else {
-                    const cplx *B = a.bk + bk_spec_index(ABL == 1 ? 0 : i, j * L + (p - 1), 0, 0, 2 * L);  // ABL 1: key index pinned (L1-resident)
-                    mac8(lane, S[0][0], z, B);
-                    mac8(lane, S[0][1], z, B + 512);
-                    mac8(lane, S[1][0], z, B + 1024);
-                    mac8(lane, S[1][1], z, B + 1536);
-                }
+                const cplx *B = a.bk + bk_spec_index(i, j * L + (p - 1), 0, 0, 2 * L);
+                mac8(lane, S[0][0], z, B);
+                mac8(lane, S[0][1], z, B + 512);
+                mac8(lane, S[1][0], z, B + 1024);
+                mac8(lane, S[1][1], z, B + 1536);
             }
         }
         wave_sync();  // every rotated read of acc precedes the updates below
@@ -184,111 +173,6 @@ __global__ __launch_bounds__(256, 2) void sk_blind_rotate_kernel(BRArgs a) {
             acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
         }
         wave_sync();
-    }
-    extract16(lane, acc, acc + 1024, a.out + job * 1025);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// blind rotate + extract, variant 2 ("one wave per SIMD"): one 64-thread workgroup = one wavefront = one job, the
-// whole 512-entry register budget.  rocprof + ablation of variant 1 showed the per-wave key loads through the
-// vector-memory path, not the arithmetic, set its pace (profiles/r01_summary.md).  Here every key chunk is requested
-// a full pipeline stage (>1000 cycles) before its use and held in registers, and the forward transform of digit
-// row r+1 (VALU + LDS exchanges) is interleaved with the multiply-accumulate of row r (VALU only), so the LDS
-// round trips of one hide behind the FMAs of the other.  The two limbs of an output column are inverse-transformed
-// side by side through two transpose buffers.  35 840 B LDS per workgroup -> 4 workgroups (one per SIMD) per CU.
-// ------------------------------------------------------------------------------------------------------
-template <int L>
-__global__ __launch_bounds__(64, 1) void sk_blind_rotate_w1_kernel(BRArgs a) {
-    __shared__ cplx sT1[512];
-    __shared__ cplx sT2[64];
-    __shared__ int32_t acc[2048];
-    __shared__ cplx xb0[kXbufSlots];
-    __shared__ cplx xb1[kXbufSlots];
-    const int lane = threadIdx.x;
-#pragma unroll
-    for (int t = 0; t < 8; t++) sT1[t * 64 + lane] = a.tw[t * 64 + lane];
-    sT2[lane] = a.tw[512 + lane];
-    const long job = blockIdx.x;
-    const int32_t *bara = a.bara + job * a.n_pad;
-    const int Bgbit = a.Bgbit;
-    const uint32_t offset = decomp_offset32(L, Bgbit);
-    constexpr int ROWS = 2 * L;
-    acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
-    wave_sync();
-
-    for (int i = 0; i < a.n; i++) {
-        const int ai = bara[i];  // wave-uniform
-        if (ai == 0) continue;   // J/bootstrap.jl:40
-        const int a2n = ai & 2047;
-        const cplx *Bi = a.bk + bk_spec_index(i, 0, 0, 0, ROWS);
-        cplx S[2][2][8];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
-        cplx B[4][8];   // the four (column, limb) chunks of the row being multiplied
-        cplx zf[8];     // row in the forward transform
-        cplx zm[8];     // transformed row being multiplied
-        uint32_t t[16];
-
-        // stage 0: request row 0's key chunks, transform row 0
-#pragma unroll
-        for (int q = 0; q < 4; q++) load8(lane, B[q], Bi + q * 512);
-        load_rotated16(lane, acc, a2n, offset, t);
-        digits_to_z(t, 1, Bgbit, zf);
-        wave_fft_fwd(lane, zf, xb0, sT1, sT2);
-
-        // stages 1 .. ROWS-1: transform row s while multiplying row s-1; refill each chunk right after its use
-#pragma unroll
-        for (int s = 1; s < ROWS; s++) {
-#pragma unroll
-            for (int m = 0; m < 8; m++) zm[m] = zf[m];
-            if (s == L) load_rotated16(lane, acc + 1024, a2n, offset, t);
-            digits_to_z(t, (s % L) + 1, Bgbit, zf);
-            const cplx *Bs = Bi + (size_t)s * 2048;
-            wave_sync();
-            fwd_seg1(lane, zf, xb0, sT1);
-            wave_sync();
-            fwd_seg2_ld(lane, zf, xb0);
-            mac8r(S[0][0], zm, B[0]);
-            load8(lane, B[0], Bs);
-            fwd_seg2_st(lane, zf, xb0, sT2);
-            wave_sync();
-            fwd_seg3_ld(lane, zf, xb0);
-            mac8r(S[0][1], zm, B[1]);
-            load8(lane, B[1], Bs + 512);
-            mac8r(S[1][0], zm, B[2]);
-            load8(lane, B[2], Bs + 1024);
-            dft8<+1>(zf);
-            mac8r(S[1][1], zm, B[3]);
-            load8(lane, B[3], Bs + 1536);
-        }
-        // drain: multiply the last row
-        mac8r(S[0][0], zf, B[0]);
-        mac8r(S[0][1], zf, B[1]);
-        mac8r(S[1][0], zf, B[2]);
-        mac8r(S[1][1], zf, B[3]);
-
-        wave_sync();  // every rotated read of acc precedes the updates below
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            inv_seg1(lane, S[c][0], xb0, sT2);
-            inv_seg1(lane, S[c][1], xb1, sT2);
-            wave_sync();
-            inv_seg2_ld(lane, S[c][0], xb0);
-            inv_seg2_ld(lane, S[c][1], xb1);
-            inv_seg2_st(lane, S[c][0], xb0);
-            inv_seg2_st(lane, S[c][1], xb1);
-            wave_sync();
-            inv_seg3_ld(lane, S[c][0], xb0);
-            inv_seg3_ld(lane, S[c][1], xb1);
-            inv_seg3_fin(lane, S[c][0], sT1);
-            inv_seg3_fin(lane, S[c][1], sT1);
-            acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
-            wave_sync();
-        }
     }
     extract16(lane, acc, acc + 1024, a.out + job * 1025);
 }
@@ -584,20 +468,12 @@ int ensure_stage(thfhe_ctx *c, size_t words) {
 
 template <int L>
 void launch_br(const BRArgs &a, hipStream_t s) {
-    const unsigned blocks = (unsigned)((a.jobs + 3) / 4);
-    static const int abl = getenv("THFHE_ABLATE") ? atoi(getenv("THFHE_ABLATE")) : 0;  // developer timing experiments only
+    // THFHE_BR_VARIANT=1 selects the first-generation kernel (one wave per job, per-wave key loads) for A/B measurements
     static const int variant = getenv("THFHE_BR_VARIANT") ? atoi(getenv("THFHE_BR_VARIANT")) : 3;
-    if (variant == 3 && abl == 0) {
+    if (variant == 1)
+        hipLaunchKernelGGL(sk_blind_rotate_kernel<L>, dim3((unsigned)((a.jobs + 3) / 4)), dim3(256), 0, s, a);
+    else
         hipLaunchKernelGGL(sk_blind_rotate_ring_kernel<L>, dim3((unsigned)((a.jobs + 7) / 8)), dim3(512), 0, s, a);
-        return;
-    }
-    if (variant == 2 && abl == 0) {
-        hipLaunchKernelGGL(sk_blind_rotate_w1_kernel<L>, dim3((unsigned)a.jobs), dim3(64), 0, s, a);
-        return;
-    }
-    if (abl == 1) hipLaunchKernelGGL((sk_blind_rotate_kernel<L, 1>), dim3(blocks), dim3(256), 0, s, a);
-    else if (abl == 2) hipLaunchKernelGGL((sk_blind_rotate_kernel<L, 2>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((sk_blind_rotate_kernel<L, 0>), dim3(blocks), dim3(256), 0, s, a);
 }
 
 // rotations (prologue + blind rotate) of `jobs` = gates * rot_per_gate jobs into c->d_u
