@@ -96,6 +96,10 @@ int thfhe_gates_dev(thfhe_ctx *ctx, int op, const int32_t *d_in0, const int32_t 
                     int32_t *d_out, size_t count);
 int thfhe_sync(thfhe_ctx *ctx);
 
+/* Batches of at most `max_jobs` rotations run on the cooperative latency kernel (one workgroup per gate), larger ones on
+ * the LDS-ring throughput kernel (eight gates per workgroup).  0 forces the ring kernel.  Default 256. */
+int thfhe_set_coop_threshold(thfhe_ctx *ctx, int max_jobs);
+
 /* Per-kernel device timing: when enabled, every *_dev call brackets each kernel with HIP events on the
  * context's stream.  After thfhe_sync, thfhe_last_timings returns milliseconds of the most recent call:
  * ms[0] = prologue (linear part + mod-switch), ms[1] = blind rotate, ms[2] = key switch, ms[3] = total. */

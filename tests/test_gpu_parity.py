@@ -57,6 +57,22 @@ def test_all_gates_bit_exact_and_truth_tables(O, sk128, gpu128):
     assert np.array_equal(gpu128.gates(thfhe.COPY, ca), ca)
 
 
+def test_every_blind_rotate_kernel_bit_exact(O, sk128, gpu128):
+    # the same 12 gates through the cooperative latency kernel (threshold >= jobs) and the LDS-ring kernel (threshold 0)
+    import thfhe
+    p, K, orc = sk128
+    a = np.array([0, 1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 0]); b = np.array([1, 1, 0, 0, 1, 0, 0, 1, 1, 0, 1, 1])
+    ca, cb = enc(O, K, a, 45), enc(O, K, b, 46)
+    ref = orc.gates(O.XOR, ca, cb)
+    try:
+        gpu128.set_coop_threshold(0)
+        assert np.array_equal(gpu128.gates(thfhe.XOR, ca, cb), ref)          # ring kernel, partially filled workgroups
+        gpu128.set_coop_threshold(1 << 20)
+        assert np.array_equal(gpu128.gates(thfhe.XOR, ca, cb), ref)          # cooperative kernel
+    finally:
+        gpu128.set_coop_threshold(256)
+
+
 def test_mux_bit_exact(O, sk128, gpu128):
     import thfhe
     p, K, orc = sk128

@@ -305,6 +305,119 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// blind rotate + extract, latency variant ("cooperative"): one 512-thread workgroup = ONE job.  For the small batches
+// the reference's gate-at-a-time callers produce (boots* shims, ripple-carry circuits) the ring kernel leaves 7/8 of a CU
+// idle; here the work of one CMux is spread over the eight waves:
+//   phase 1  waves 0 .. 2l-1: wave r rotates/decomposes/transforms digit row r and publishes its spectrum in LDS;
+//            meanwhile waves 0..3 already have their key chunks (row r, column c, limb h) in flight (2l x 8 loads);
+//   phase 2  waves 0..3 = (column c, limb h): S = sum_r spectrum_r * key(r, c, h), inverse transform;
+//            the hi-limb wave hands round(hi) to the lo-limb wave of its column, which updates the accumulator.
+// Three workgroup barriers per CMux.  LDS: T1 8 + acc 8 + spectra 2l x 8 + 8 transpose buffers x 8 + hi-limb 8 KiB.
+// ------------------------------------------------------------------------------------------------------
+// two independent forward transforms interleaved segment by segment (two transpose buffers): the LDS round trips of one
+// overlap the butterflies of the other when the wave is alone on its SIMD
+__device__ __forceinline__ void wave_fft_fwd_s2(int lane, cplx (&za)[8], cplx (&zb)[8], cplx *xa, cplx *xbb, const cplx *T1, const W64 &w) {
+    wave_sync();
+    fwds_seg1(lane, za, xa, T1);
+    fwds_seg1(lane, zb, xbb, T1);
+    wave_sync();
+    fwds_seg2_ld(lane, za, xa);
+    fwds_seg2_ld(lane, zb, xbb);
+    fwds_seg2_st(lane, za, xa, w);
+    fwds_seg2_st(lane, zb, xbb, w);
+    wave_sync();
+    fwds_seg3(lane, za, xa);
+    fwds_seg3(lane, zb, xbb);
+}
+
+template <int L>
+__global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) {
+    constexpr int ROWS = 2 * L;
+    __shared__ cplx sT1[512];
+    __shared__ int32_t sAcc[2048];
+    __shared__ cplx sSpec[ROWS][512];
+    __shared__ cplx sX[8][512];
+    __shared__ uint32_t sHi[2][1024];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    sT1[threadIdx.x] = a.tw[threadIdx.x];
+    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)], a.tw[512 + 2 * 8 + (lane & 7)], a.tw[512 + 4 * 8 + (lane & 7)]};
+    const long job = blockIdx.x;
+    const int32_t *bara = a.bara + job * a.n_pad;
+    const int Bgbit = a.Bgbit;
+    const uint32_t offset = decomp_offset32(L, Bgbit);
+    if (wave == 0) acc_init16(lane, sAcc, sAcc + 1024, a.barb[job], a.mu);
+    __syncthreads();
+    // roles: waves 0..3 transform digit rows (wave w: row w, and row w+4 if it exists); waves 4..7 = (column c, limb h)
+    const int c = (wave >> 1) & 1, h = wave & 1;
+
+    for (int i = 0; i < a.n; i++) {
+        const int ai = bara[i];  // uniform over the workgroup
+        if (ai == 0) continue;   // J/bootstrap.jl:40
+        const int a2n = ai & 2047;
+        if (wave < 4) {
+            if (wave < ROWS) {
+                uint32_t t[16];
+                cplx za[8];
+                load_rotated16(lane, sAcc + (wave / L) * 1024, a2n, offset, t);
+                digits_to_z(t, (wave % L) + 1, Bgbit, za);
+                if (wave + 4 < ROWS) {
+                    cplx zb[8];
+                    const int r2 = wave + 4;
+                    if (r2 / L != wave / L) load_rotated16(lane, sAcc + (r2 / L) * 1024, a2n, offset, t);
+                    digits_to_z(t, (r2 % L) + 1, Bgbit, zb);
+                    wave_fft_fwd_s2(lane, za, zb, sX[wave], sX[wave + 4], sT1, w64);
+#pragma unroll
+                    for (int m = 0; m < 8; m++) sSpec[r2][m * 64 + lane] = zb[m];
+                } else {
+                    wave_fft_fwd_s(lane, za, sX[wave], sT1, w64);
+                }
+#pragma unroll
+                for (int m = 0; m < 8; m++) sSpec[wave][m * 64 + lane] = za[m];
+            }
+            __syncthreads();  // spectra published
+            __syncthreads();  // (multiply / inverse phase of waves 4..7)
+        } else {
+            // key chunks of this wave's (c, h) for every row: in flight while waves 0..3 transform
+            cplx B[ROWS][8];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) load8(lane, B[r], a.bk + bk_spec_index(i, r, c, h, ROWS));
+            __syncthreads();  // spectra published
+            cplx S[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) S[m] = cplx{0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                cplx z[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) z[m] = sSpec[r][m * 64 + lane];
+                mac8r(S, z, B[r]);
+            }
+            wave_fft_inv_s(lane, S, sX[wave], sT1, w64);
+            if (h == 1) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    sHi[c][lane + 64 * m] = round_lo32(S[m].re);
+                    sHi[c][lane + 64 * m + 512] = round_lo32(S[m].im);
+                }
+            }
+            __syncthreads();  // hi limbs published
+            if (h == 0) {
+                int32_t *ap = sAcc + c * 1024;
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const int q = lane + 64 * m;
+                    ap[q] = (int32_t)((uint32_t)ap[q] + round_lo32(S[m].re) + (sHi[c][q] << 16));
+                    ap[q + 512] = (int32_t)((uint32_t)ap[q + 512] + round_lo32(S[m].im) + (sHi[c][q + 512] << 16));
+                }
+            }
+        }
+        __syncthreads();  // accumulator updated before anybody rotates it again
+    }
+    if (wave == 0) extract16(lane, sAcc, sAcc + 1024, a.out + job * 1025);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // key switch.  One workgroup (4 waves) per gate; wave w takes input coordinates i = w (mod 4); every lane keeps
 // its 4*NX4 + 2*NX2 words of the padded output row in registers.  KSK rows are padded to 64*(4*NX4+2*NX2) words
 // (n = 630: 640 words = 2560 B, 16-B aligned): per row each lane issues NX4 16-byte and NX2 8-byte loads.
@@ -419,6 +532,7 @@ struct thfhe_ctx {
     cplx *d_bk = nullptr;     // spectral key
     int32_t *d_ksk = nullptr; // padded rows
     int ks_w = 0;             // words per lane of a padded KSK row
+    int coop_max_jobs = 256;  // batches up to this many rotations use the cooperative (latency) kernel
     cplx *d_tw = nullptr;
     // workspace
     size_t cap_jobs = 0;
@@ -467,11 +581,14 @@ int ensure_stage(thfhe_ctx *c, size_t words) {
 }
 
 template <int L>
-void launch_br(const BRArgs &a, hipStream_t s) {
-    // THFHE_BR_VARIANT=1 selects the first-generation kernel (one wave per job, per-wave key loads) for A/B measurements
-    static const int variant = getenv("THFHE_BR_VARIANT") ? atoi(getenv("THFHE_BR_VARIANT")) : 3;
+void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
+    // THFHE_BR_VARIANT=1 selects the first-generation kernel (one wave per job, per-wave key loads) for A/B measurements;
+    // =3 / =4 force the ring / cooperative kernel.  Default: cooperative (latency) kernel for small batches, ring otherwise.
+    static const int variant = getenv("THFHE_BR_VARIANT") ? atoi(getenv("THFHE_BR_VARIANT")) : 0;
     if (variant == 1)
         hipLaunchKernelGGL(sk_blind_rotate_kernel<L>, dim3((unsigned)((a.jobs + 3) / 4)), dim3(256), 0, s, a);
+    else if (variant == 4 || (variant == 0 && a.jobs <= coop_max))
+        hipLaunchKernelGGL(sk_blind_rotate_coop_kernel<L>, dim3((unsigned)a.jobs), dim3(512), 0, s, a);
     else
         hipLaunchKernelGGL(sk_blind_rotate_ring_kernel<L>, dim3((unsigned)((a.jobs + 7) / 8)), dim3(512), 0, s, a);
 }
@@ -490,10 +607,10 @@ int enqueue_rotations(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[1], c->stream));
     BRArgs a{c->d_bk, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)jobs, n, c->n_pad, c->p.Bgbit, mu};
     switch (c->p.l) {
-    case 1: launch_br<1>(a, c->stream); break;
-    case 2: launch_br<2>(a, c->stream); break;
-    case 3: launch_br<3>(a, c->stream); break;
-    case 4: launch_br<4>(a, c->stream); break;
+    case 1: launch_br<1>(a, c->stream, c->coop_max_jobs); break;
+    case 2: launch_br<2>(a, c->stream, c->coop_max_jobs); break;
+    case 3: launch_br<3>(a, c->stream, c->coop_max_jobs); break;
+    case 4: launch_br<4>(a, c->stream, c->coop_max_jobs); break;
     default: return thfhe_fail(THFHE_E_UNSUPPORTED, "decomposition length l must be 1..4");
     }
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[2], c->stream));
@@ -668,6 +785,11 @@ int thfhe_reserve(thfhe_ctx *c, size_t max_count) {
 int thfhe_sync(thfhe_ctx *c) {
     if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
     THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+int thfhe_set_coop_threshold(thfhe_ctx *c, int max_jobs) {
+    if (!c || max_jobs < 0) return thfhe_fail(THFHE_E_INVALID, "bad argument");
+    c->coop_max_jobs = max_jobs;
     return THFHE_OK;
 }
 int thfhe_set_profiling(thfhe_ctx *c, int enabled) {

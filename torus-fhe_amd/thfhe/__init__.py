@@ -75,6 +75,7 @@ SIGNATURES = {
     "thfhe_reserve": (C.c_int, [_vp, C.c_size_t]),
     "thfhe_gates_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
     "thfhe_sync": (C.c_int, [_vp]),
+    "thfhe_set_coop_threshold": (C.c_int, [_vp, C.c_int]),
     "thfhe_set_profiling": (C.c_int, [_vp, C.c_int]),
     "thfhe_last_timings": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "thfhe_mk_ctx_create": (C.c_int, [C.POINTER(Params), _i64p, _i32p, C.c_int, C.POINTER(_vp)]),
@@ -234,6 +235,10 @@ class CloudKey:
 
     def sync(self):
         _check(lib().thfhe_sync(self.h))
+
+    def set_coop_threshold(self, max_jobs):
+        """Batches of <= max_jobs rotations use the cooperative latency kernel; 0 forces the LDS-ring kernel."""
+        _check(lib().thfhe_set_coop_threshold(self.h, int(max_jobs)))
 
     def set_profiling(self, on):
         _check(lib().thfhe_set_profiling(self.h, int(bool(on))))
