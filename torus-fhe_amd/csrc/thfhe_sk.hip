@@ -436,6 +436,7 @@ struct KSArgs {
     long gates;
     int rot_per_gate;    // 1, or 2 for MUX: input = (0, 2^29) + u1 + u2     (J/gates.jl:172-176)
     int n, t, basebit;
+    int nsplit;          // > 1: grid.y workgroups share one gate (small batches) and accumulate into a zeroed output with atomics
 };
 
 template <int NX4, int NX2>
@@ -462,7 +463,8 @@ __global__ __launch_bounds__(256) void sk_keyswitch_kernel(KSArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; q++) r4[c][q] = 0;
     r2[0][0] = r2[0][1] = 0;
-    for (int i = wave; i < 1024; i += 4) {
+    const int i_lo = (int)blockIdx.y * (1024 / a.nsplit), i_hi = i_lo + 1024 / a.nsplit;
+    for (int i = i_lo + wave; i < i_hi; i += 4) {
         const uint32_t ai = sA[i];
         const int32_t *rowi = a.ksk + (size_t)i * a.t * base1 * ROW;
         for (int j = 0; j < a.t; j++) {
@@ -498,8 +500,10 @@ __global__ __launch_bounds__(256) void sk_keyswitch_kernel(KSArgs a) {
         int32_t *out = a.out + (size_t)g * (a.n + 1);
         auto emit = [&](int q, uint32_t v) {
             v += sRed[0][q] + sRed[1][q] + sRed[2][q];
-            if (q == a.n) v += b;
-            if (q <= a.n) out[q] = (int32_t)v;
+            if (q == a.n && blockIdx.y == 0) v += b;
+            if (q > a.n) return;
+            if (a.nsplit == 1) out[q] = (int32_t)v;
+            else atomicAdd(reinterpret_cast<unsigned int *>(out) + q, v);  // integer adds commute: still bit-exact
         };
 #pragma unroll
         for (int c = 0; c < NX4; c++)
@@ -532,7 +536,7 @@ struct thfhe_ctx {
     cplx *d_bk = nullptr;     // spectral key
     int32_t *d_ksk = nullptr; // padded rows
     int ks_w = 0;             // words per lane of a padded KSK row
-    int coop_max_jobs = 256;  // batches up to this many rotations use the cooperative (latency) kernel
+    int coop_max_jobs = 768;  // batches up to this many rotations use the cooperative (latency) kernel (measured crossover ~1000)
     cplx *d_tw = nullptr;
     // workspace
     size_t cap_jobs = 0;
@@ -619,8 +623,10 @@ int enqueue_rotations(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1
 }
 
 int enqueue_keyswitch(thfhe_ctx *c, const int32_t *d_u, int32_t *d_out, size_t gates, int rot_per_gate, bool timed) {
-    KSArgs k{c->d_ksk, d_u, d_out, (long)gates, rot_per_gate, c->p.n, c->p.ks_t, c->p.ks_basebit};
-    const dim3 grid((unsigned)gates), block(256);
+    const int nsplit = gates <= 32 ? 16 : (gates <= 128 ? 8 : (gates <= 512 ? 2 : 1));  // fill the chip at small batch sizes
+    KSArgs k{c->d_ksk, d_u, d_out, (long)gates, rot_per_gate, c->p.n, c->p.ks_t, c->p.ks_basebit, nsplit};
+    if (nsplit > 1) THFHE_HIP(hipMemsetAsync(d_out, 0, gates * (size_t)(c->p.n + 1) * sizeof(int32_t), c->stream));
+    const dim3 grid((unsigned)gates, (unsigned)nsplit), block(256);
     switch (c->ks_w) {
 #define THFHE_KS_CASE(W, X4, X2) \
     case W: hipLaunchKernelGGL((sk_keyswitch_kernel<X4, X2>), grid, block, 0, c->stream, k); break;
