@@ -80,6 +80,9 @@ int thfhe_ctx_params(const thfhe_ctx *ctx, thfhe_params *out);
  * an input (the reference's callers do, src/KNN_medical_data.cpp:256,395).  Thread-safe per ctx. */
 int thfhe_gates(thfhe_ctx *ctx, int op, const int32_t *in0, const int32_t *in1, const int32_t *in2,
                 int32_t *out, size_t count);
+/* One launch for a level of a gate DAG: gate g applies ops[g] (any two-input bootstrapped gate NAND..ORYN) to
+ * (in0[g], in1[g]).  ops is a HOST array of `count` opcodes. */
+int thfhe_gates_mixed(thfhe_ctx *ctx, const int32_t *ops, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count);
 int thfhe_bootstrap(thfhe_ctx *ctx, int32_t mu, const int32_t *x, int32_t *out, size_t count);
 int thfhe_bootstrap_wo_keyswitch(thfhe_ctx *ctx, int32_t mu, const int32_t *x, int32_t *out_N1, size_t count);
 int thfhe_keyswitch(thfhe_ctx *ctx, const int32_t *in_N1, int32_t *out, size_t count);

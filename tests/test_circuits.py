@@ -1,0 +1,93 @@
+"""Gate-DAG front end (torus-fhe_amd/thfhe/circuits.py): the reference's KNN building blocks as static gate lists.
+CPU part: gate census against SURVEY.md appendix D / src/KNN_medical_data.cpp, plaintext simulation of the wiring,
+level structure.  GPU part: the circuits on the reference's fixture ciphertexts."""
+import numpy as np
+import pytest
+
+
+def bits_msb(v, nb=32):
+    return [(v >> (nb - 1 - i)) & 1 for i in range(nb)]
+
+
+def from_bits(b):
+    v = 0
+    for x in b:
+        v = (v << 1) | int(bool(x))
+    return v
+
+
+def build_distance():
+    from thfhe import circuits as Cc
+    cir = Cc.Circuit()
+    x, y, all_one, lsb_one = (cir.inputs(32) for _ in range(4))
+    zero = cir.inputs(1)[0]
+    out = Cc.distance(cir, x, y, all_one, lsb_one, zero)
+    return cir, out
+
+
+def test_census_matches_reference_structure():
+    from thfhe import circuits as Cc
+    import thfhe
+    cir = Cc.Circuit()
+    a, b = cir.inputs(32), cir.inputs(32)
+    zero = cir.inputs(1)[0]
+    Cc.full_adder(cir, a, b, zero)
+    ops = [g[0] for g in cir.gates]
+    assert (ops.count(thfhe.XOR), ops.count(thfhe.AND), ops.count(thfhe.OR)) == (64, 64, 31)      # FullAdder(32) = 159 gates
+    cir, _ = build_distance()
+    cs = cir.census()
+    assert cs["gates"] == 2 * (32 + 2 * 159) + 32 and cs["mux"] == 32 and cs["rotations"] == 700 + 64   # distance = 2 difference + 32 MUX
+    # ripple carry costs 2 dependent gate levels per bit (AND, OR); the second adder pipelines behind the first, so the
+    # ASAP depth is ~2*32 + a few, against 732 sequential boots* calls in the reference
+    assert 64 <= cs["depth"] <= 72
+    widths = [len(l) for l in cir.levels()]
+    assert max(widths) >= 128       # the independent first levels of both differences are batched together
+
+
+def test_plaintext_simulation_of_reference_circuits():
+    from thfhe import circuits as Cc
+    rng = np.random.default_rng(0)
+    cir, out = build_distance()
+    for xa, ya in [(9876, 686), (686, 9876), (0, 0), (123456789, 987654321), (2**31 - 1, 1)] + [tuple(int(v) for v in rng.integers(0, 2**31, 2)) for _ in range(5)]:
+        bits = bits_msb(xa) + bits_msb(ya) + [1] * 32 + bits_msb(1) + [0]
+        v = Cc.simulate(cir, bits)
+        assert from_bits(v[out]) == abs(xa - ya)
+    # distance_bw_data over 3 columns (column 0 is skipped by the reference, :257)
+    cir = Cc.Circuit()
+    ra = [cir.inputs(16) for _ in range(3)]
+    rb = [cir.inputs(16) for _ in range(3)]
+    all_zero, all_one, lsb_one = cir.inputs(16), cir.inputs(16), cir.inputs(16)
+    zero = cir.inputs(1)[0]
+    res = Cc.distance_bw_data(cir, ra, rb, all_zero, all_one, lsb_one, zero)
+    va, vb = [7, 1000, 30], [9, 400, 75]
+    bits = sum((bits_msb(x, 16) for x in va), []) + sum((bits_msb(x, 16) for x in vb), []) + [0] * 16 + [1] * 16 + bits_msb(1, 16) + [0]
+    assert from_bits(Cc.simulate(cir, bits)[res]) == abs(1000 - 400) + abs(30 - 75)
+
+
+@pytest.mark.gpu
+def test_distance_circuit_on_reference_ciphertexts(O, sk128):
+    """distance(cloud1, cloud2) (src/KNN_medical_data.cpp:217-236) on the reference's fixture ciphertexts and constants
+    (allOne.data, lsbOne.data): |9876 - 686| = 9190 = diff.txt; levelised evaluation; sampled gates bit-exact vs the oracle."""
+    import thfhe
+    from thfhe import circuits as Cc
+    p, K, orc = sk128
+    ck = thfhe.CloudKey(thfhe.make_params("SK-128"), K.bk, K.ksk, device=0)
+    _, c1, _ = O.load_fixture_records("cloud1.data")
+    _, c2, _ = O.load_fixture_records("cloud2.data")
+    _, all_one, _ = O.load_fixture_records("allOne.data")
+    _, lsb_one, _ = O.load_fixture_records("lsbOne.data")
+    _, lsb_zero, _ = O.load_fixture_records("lsbZero.data")
+    cir, out = build_distance()
+    inputs = np.concatenate([c1, c2, all_one, lsb_one, lsb_zero[31:32]])     # carry-in = LSB of lsbZero.data = Enc(0)
+    stats = {}
+    vals = Cc.evaluate(ck, cir, inputs, stats)
+    assert O.bits_to_int_msb_first(K.decrypt_bits(vals[out])) == 9190
+    assert stats["launches"] < stats["gates"] / 3        # batching really happened
+    rng = np.random.default_rng(1)
+    picks = rng.choice(len(cir.gates), 24, replace=False)
+    for op in set(cir.gates[g][0] for g in picks):
+        gs = [g for g in picks if cir.gates[g][0] == op]
+        a = vals[[cir.gates[g][1] for g in gs]]; b = vals[[cir.gates[g][2] for g in gs]]
+        c = vals[[cir.gates[g][3] for g in gs]] if op == thfhe.MUX else None
+        assert np.array_equal(vals[cir.n_inputs + np.array(gs)], orc.gates(op, a, b, c))
+    ck.close()

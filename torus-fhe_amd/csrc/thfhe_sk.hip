@@ -79,16 +79,16 @@ __host__ __device__ inline bool gate_lin(int op, int which, Lin &L) {
 }
 
 __global__ __launch_bounds__(256) void sk_prologue_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ in1,
-                                                           const int32_t *__restrict__ in2, int op, int rot_per_gate, int n,
-                                                           int n_pad, int log2_2n, long jobs, int32_t *__restrict__ bara,
-                                                           int32_t *__restrict__ barb) {
+                                                           const int32_t *__restrict__ in2, int op, const int32_t *__restrict__ ops,
+                                                           int rot_per_gate, int n, int n_pad, int log2_2n, long jobs,
+                                                           int32_t *__restrict__ bara, int32_t *__restrict__ barb) {
     const long job = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (job >= jobs || i > n) return;
     const long gate = job / rot_per_gate;
     const int which = (int)(job % rot_per_gate);
     Lin L;
-    gate_lin(op, which, L);
+    gate_lin(ops ? ops[gate] : op, which, L);  // ops: per-gate opcodes of a mixed level (validated on the host)
     const size_t off = (size_t)gate * (n + 1) + i;
     uint32_t v = (uint32_t)L.cx * (uint32_t)in0[off];
     if (L.cy != 0) v += (uint32_t)L.cy * (uint32_t)(L.ysel == 2 ? in2[off] : in1[off]);
@@ -599,14 +599,14 @@ void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
 
 // rotations (prologue + blind rotate) of `jobs` = gates * rot_per_gate jobs into c->d_u
 int enqueue_rotations(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1, const int32_t *d2, size_t gates,
-                      int rot_per_gate, int32_t mu) {
+                      int rot_per_gate, int32_t mu, const int32_t *d_ops = nullptr) {
     const size_t jobs = gates * rot_per_gate;
     int rc = ensure_workspace(c, jobs);
     if (rc) return rc;
     const int n = c->p.n;
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[0], c->stream));
     dim3 pg((unsigned)((n + 1 + 255) / 256), (unsigned)jobs);
-    hipLaunchKernelGGL(sk_prologue_kernel, pg, dim3(256), 0, c->stream, d0, d1, d2, op, rot_per_gate, n, c->n_pad,
+    hipLaunchKernelGGL(sk_prologue_kernel, pg, dim3(256), 0, c->stream, d0, d1, d2, op, d_ops, rot_per_gate, n, c->n_pad,
                        ilog2(2 * c->p.N), (long)jobs, c->d_bara, c->d_barb);
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[1], c->stream));
     BRArgs a{c->d_bk, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)jobs, n, c->n_pad, c->p.Bgbit, mu};
@@ -835,6 +835,28 @@ int thfhe_gates(thfhe_ctx *c, int op, const int32_t *in0, const int32_t *in1, co
     rc = gates_dev_locked(c, op, c->d_in[0], in1 ? c->d_in[1] : nullptr, in2 ? c->d_in[2] : nullptr, c->d_out, count);
     if (rc) return rc;
     THFHE_HIP(hipMemcpyAsync(out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));  // after all input copies: aliasing-safe
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+int thfhe_gates_mixed(thfhe_ctx *c, const int32_t *ops, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count) {
+    if (!c || !ops || !in0 || !in1 || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    for (size_t g = 0; g < count; g++)
+        if (ops[g] < THFHE_NAND || ops[g] > THFHE_ORYN) return thfhe_fail(THFHE_E_INVALID, "thfhe_gates_mixed takes two-input bootstrapped gates only");
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t words = count * (c->p.n + 1), bytes = words * sizeof(int32_t);
+    int rc = ensure_stage(c, words);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(c->d_in[0], in0, bytes, hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_in[1], in1, bytes, hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_in[2], ops, count * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));  // staging buffer 2 holds the opcodes
+    rc = enqueue_rotations(c, THFHE_NAND, c->d_in[0], c->d_in[1], nullptr, count, 1, 1 << 29, c->d_in[2]);
+    if (rc) return rc;
+    rc = enqueue_keyswitch(c, c->d_u, c->d_out, count, 1, true);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     THFHE_HIP(hipStreamSynchronize(c->stream));
     return THFHE_OK;
 }

@@ -65,6 +65,7 @@ SIGNATURES = {
     "thfhe_ctx_destroy": (None, [_vp]),
     "thfhe_ctx_params": (C.c_int, [_vp, C.POINTER(Params)]),
     "thfhe_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
+    "thfhe_gates_mixed": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_bootstrap": (C.c_int, [_vp, C.c_int32, _i32p, _i32p, C.c_size_t]),
     "thfhe_bootstrap_wo_keyswitch": (C.c_int, [_vp, C.c_int32, _i32p, _i32p, C.c_size_t]),
     "thfhe_keyswitch": (C.c_int, [_vp, _i32p, _i32p, C.c_size_t]),
@@ -191,6 +192,15 @@ class CloudKey:
         z = _rec(z, self.words) if z is not None else None
         out = np.empty_like(x)
         _check(lib().thfhe_gates(self.h, op, _p32(x), _p32(y), _p32(z), _p32(out), x.shape[0]))
+        return out
+
+    def gates_mixed(self, ops, x, y):
+        """One launch for a DAG level: gate g applies ops[g] (two-input bootstrapped gates) to (x[g], y[g])."""
+        x, y = _rec(x, self.words), _rec(y, self.words)
+        ops = np.ascontiguousarray(ops, np.int32)
+        assert ops.shape[0] == x.shape[0] == y.shape[0]
+        out = np.empty_like(x)
+        _check(lib().thfhe_gates_mixed(self.h, _p32(ops), _p32(x), _p32(y), _p32(out), x.shape[0]))
         return out
 
     def bootstrap(self, x, mu=MU8):

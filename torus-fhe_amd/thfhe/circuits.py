@@ -1,0 +1,154 @@
+"""Gate-DAG front end: the reference's circuits as static gate lists + a levelising evaluator.
+
+The reference's applications issue long dependent streams of two-input gates, one `boots*` call at a time
+(FullAdder / difference / distance / distance_bw_data, src/KNN_medical_data.cpp:127-263; mk_add_3gen,
+3gen_mk_gates.jl:183-220).  Here the same wiring is recorded as a DAG, scheduled ASAP into levels, and every level is
+evaluated as ONE batched launch (thfhe_gates_mixed for the two-input gates, thfhe_gates for the MUXes) so that the
+independent gates of a level -- and of independent sub-circuits placed in the same DAG -- fill the GPU.
+
+Bit vectors are MSB-first lists of wire ids, as in the reference (index nbits-1 = least significant bit,
+src/bootstrap_modules.cpp:95).
+"""
+import numpy as np
+
+from . import AND, MUX, NOT, OR, XOR
+
+
+class Circuit:
+    """A static gate list.  Wires are integers; inputs are declared first, every gate defines one new wire."""
+
+    def __init__(self):
+        self.n_inputs = 0
+        self.gates = []   # (op, a, b, c) ; c = -1 unless MUX ; output wire id = n_inputs + index
+        self.outputs = {}
+
+    def inputs(self, count):
+        assert not self.gates, "declare all inputs before the first gate"
+        ids = list(range(self.n_inputs, self.n_inputs + count))
+        self.n_inputs += count
+        return ids
+
+    def gate(self, op, a, b=-1, c=-1):
+        self.gates.append((op, a, b, c))
+        return self.n_inputs + len(self.gates) - 1
+
+    def n_wires(self):
+        return self.n_inputs + len(self.gates)
+
+    def levels(self):
+        """ASAP schedule: list of lists of gate indices; NOT costs no level (it is not bootstrapped, gates.jl:76-79)."""
+        depth = np.zeros(self.n_wires(), np.int64)
+        lv = {}
+        for gi, (op, a, b, c) in enumerate(self.gates):
+            d = max(depth[w] for w in (a, b, c) if w >= 0)
+            if op != NOT:
+                d += 1
+            depth[self.n_inputs + gi] = d
+            lv.setdefault((int(d), op == NOT), []).append(gi)
+        keys = sorted(lv)  # (depth, is_not): bootstrapped gates of depth d first, then the free NOTs that read them
+        return [lv[k] for k in keys]
+
+    def census(self):
+        ops = [g[0] for g in self.gates]
+        boot = sum(1 for o in ops if o not in (NOT,))
+        return dict(gates=len(ops), bootstrapped=boot, mux=ops.count(MUX), rotations=boot + ops.count(MUX),
+                    depth=len([l for l in self.levels() if self.gates[l[0]][0] != NOT]))
+
+
+# ---- the reference's building blocks (src/KNN_medical_data.cpp) ---------------------------------------------------
+def ones_comp(cir, all_one, x):
+    """onesComp, :127-132."""
+    return [cir.gate(XOR, all_one[i], x[i]) for i in range(len(x))]
+
+
+def full_adder(cir, a, b, carry_in):
+    """FullAdder, :134-157 (same wiring as src/bootstrap_modules.cpp:20-44).  Returns (sum, carry) MSB-first; carry[nb-1] = carry_in."""
+    nb = len(a)
+    sum2 = [None] * nb
+    carry = [None] * nb
+    carry[nb - 1] = carry_in
+    for i in range(nb - 1, -1, -1):
+        s1 = cir.gate(XOR, a[i], b[i])
+        c1 = cir.gate(AND, a[i], b[i])
+        sum2[i] = cir.gate(XOR, s1, carry[i])
+        c2 = cir.gate(AND, s1, carry[i])
+        if i != 0:
+            carry[i - 1] = cir.gate(OR, c1, c2)
+    return sum2, carry
+
+
+def difference(cir, x, y, all_one, lsb_one, zero):
+    """difference = x - y via two's complement, :161-213."""
+    ones = ones_comp(cir, all_one, y)
+    twos, _ = full_adder(cir, ones, lsb_one, zero)
+    diff, _ = full_adder(cir, x, twos, zero)
+    return diff
+
+
+def distance(cir, x, y, all_one, lsb_one, zero):
+    """|x - y|: dist[i] = MUX(d1[0], d2[i], d1[i]), :217-236."""
+    d1 = difference(cir, x, y, all_one, lsb_one, zero)
+    d2 = difference(cir, y, x, all_one, lsb_one, zero)
+    return [cir.gate(MUX, d1[0], d2[i], d1[i]) for i in range(len(x))]
+
+
+def distance_bw_data(cir, row_a, row_b, all_zero, all_one, lsb_one, zero):
+    """Manhattan distance of two records, columns 1..end, :239-263."""
+    result = list(all_zero)
+    for col in range(1, len(row_a)):
+        dist = distance(cir, row_a[col], row_b[col], all_one, lsb_one, zero)
+        result, _ = full_adder(cir, result, dist, zero)
+    return result
+
+
+def simulate(cir, input_bits):
+    """Plaintext evaluation of the DAG (wiring check): bool[n_inputs] -> bool[n_wires]."""
+    from . import ANDNY, ANDYN, NAND, NOR, ORNY, ORYN, XNOR
+    v = np.zeros(cir.n_wires(), bool)
+    v[:cir.n_inputs] = np.asarray(input_bits, bool)
+    f = {NAND: lambda a, b: not (a and b), OR: lambda a, b: a or b, AND: lambda a, b: a and b, XOR: lambda a, b: a != b,
+         XNOR: lambda a, b: a == b, NOR: lambda a, b: not (a or b), ANDNY: lambda a, b: (not a) and b,
+         ANDYN: lambda a, b: a and (not b), ORNY: lambda a, b: (not a) or b, ORYN: lambda a, b: a or (not b)}
+    for gi, (op, a, b, c) in enumerate(cir.gates):
+        o = cir.n_inputs + gi
+        if op == NOT:
+            v[o] = not v[a]
+        elif op == MUX:
+            v[o] = v[b] if v[a] else v[c]
+        else:
+            v[o] = f[op](bool(v[a]), bool(v[b]))
+    return v
+
+
+# ---- evaluator --------------------------------------------------------------------------------------------------------
+def evaluate(ck, cir, input_records, stats=None):
+    """Run the DAG on the engine.  input_records: int32[n_inputs][n+1].  Returns int32[n_wires][n+1]."""
+    words = ck.words
+    vals = np.zeros((cir.n_wires(), words), np.int32)
+    vals[:cir.n_inputs] = np.asarray(input_records, np.int32).reshape(cir.n_inputs, words)
+    gates = cir.gates
+    base = cir.n_inputs
+    launches = 0
+    for level in cir.levels():
+        op0 = gates[level[0]][0]
+        if op0 == NOT:
+            for g in level:   # in gate order: a NOT may read another NOT of the same depth
+                vals[base + g] = (0 - vals[gates[g][1]].astype(np.int64)).astype(np.int32)
+            continue
+        two = [g for g in level if gates[g][0] != MUX]
+        mux = [g for g in level if gates[g][0] == MUX]
+        if two:
+            ops = np.array([gates[g][0] for g in two], np.int32)
+            a = vals[[gates[g][1] for g in two]]
+            b = vals[[gates[g][2] for g in two]]
+            vals[base + np.array(two)] = ck.gates_mixed(ops, a, b)
+            launches += 1
+        if mux:
+            a = vals[[gates[g][1] for g in mux]]
+            b = vals[[gates[g][2] for g in mux]]
+            c = vals[[gates[g][3] for g in mux]]
+            vals[base + np.array(mux)] = ck.gates(MUX, a, b, c)
+            launches += 1
+    if stats is not None:
+        stats.update(cir.census(), launches=launches)
+    return vals
