@@ -140,18 +140,15 @@ struct MKBRArgs {
     int64_t mu;
 };
 
-template <int L>
-__global__ __launch_bounds__(512, 2) void mk_blind_rotate_ring_kernel(MKBRArgs a) {
-    __shared__ cplx sT1[512];
-    __shared__ int64_t sAcc[4][2048];
-    __shared__ cplx sX[8][512];
-    __shared__ cplx sRing[3][512];
+// The role o (output polynomial: 0 = c1' mask, 1 = c0' body) is a template parameter so that each role's code keeps its four
+// limb spectra in fixed registers; waves w and w+4 of a workgroup take roles 0 and 1 of gate w & 3 and share a SIMD, so exactly
+// one of them multiplies at every chunk step.
+template <int L, int O>
+__device__ __forceinline__ void mk_blind_rotate_role(const MKBRArgs &a, cplx *sT1, int64_t (*sAcc)[2048], cplx (*sX)[512], cplx (*sRing)[512],
+                                                     int wave, int lane) {
     constexpr int ROWS = 2 * L;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    constexpr int o = O;
     const int g = wave & 3;   // gate within the workgroup
-    const int o = wave >> 2;  // output polynomial: 0 = c1' (mask), 1 = c0' (body); waves w and w+4 share a SIMD
-    sT1[threadIdx.x] = a.tw[threadIdx.x];
     const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)], a.tw[512 + 2 * 8 + (lane & 7)], a.tw[512 + 4 * 8 + (lane & 7)]};
     const long job = (long)blockIdx.x * 4 + g;
     const bool has_job = job < a.jobs;
@@ -219,6 +216,19 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_ring_kernel(MKBRArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (has_job && o == 0) extract16_64(lane, acc, acc + 1024, a.out + job * 1025);
+}
+
+template <int L>
+__global__ __launch_bounds__(512, 2) void mk_blind_rotate_ring_kernel(MKBRArgs a) {
+    __shared__ cplx sT1[512];
+    __shared__ int64_t sAcc[4][2048];
+    __shared__ cplx sX[8][512];
+    __shared__ cplx sRing[3][512];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    sT1[threadIdx.x] = a.tw[threadIdx.x];
+    if (wave < 4) mk_blind_rotate_role<L, 0>(a, sT1, sAcc, sX, sRing, wave, lane);
+    else mk_blind_rotate_role<L, 1>(a, sT1, sAcc, sX, sRing, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------
