@@ -93,6 +93,8 @@ def cpu_baseline(K, p_name, xa, xb, gpu_out, sample):
     """Time the CPU oracle (exact-integer restatement of the reference path, OpenMP over gates) on the first
     `sample` gates of the same workload, on this host's cores; also cross-check the GPU output on them."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = len(os.sched_getaffinity(0))
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # one oracle thread per core this process may run on (set before libgomp loads)
     import oracle_lib as O
     p = O.make_params(p_name)
     orc = O.Oracle(p, K.bk, K.ksk)
@@ -103,7 +105,8 @@ def cpu_baseline(K, p_name, xa, xb, gpu_out, sample):
     dt = time.perf_counter() - t0
     exact = bool(np.array_equal(ref, gpu_out[:sample]))
     return dict(value=sample / dt, unit="gates/s", cores=threads, kind="port",
-                sample=f"first {sample} NAND gates of the same batch, oracle NTT path, OpenMP schedule(dynamic) over gates, {dt:.2f} s wall",
+                sample=f"first {sample} NAND gates of the same batch, exact-integer oracle (64-bit NTT path, not libtfhe's AVX FFT), "
+                       f"OpenMP schedule(dynamic) over gates on {threads} threads, {dt:.2f} s wall",
                 gpu_bit_exact_on_sample=exact)
 
 

@@ -55,6 +55,35 @@ __device__ __forceinline__ void wave_fft_inv(int lane, cplx (&z)[8], cplx *xb, c
     wave_sync();
     inv_seg3(lane, z, xb, T1);
 }
+// ---- LDS key ring (shared by the single-key and multi-key ring kernels) --------------------------------------------
+// One LDS-DMA of this wave's 1 KiB slice of a key chunk: lane l fetches 16 B at gptr_lane into LDS at lds_byte_off + 16 l.
+// Inline asm on purpose: the compiler then neither waits vmcnt(0) before every ring read nor reorders the hand-off.
+__device__ __forceinline__ void ring_dma(const cplx *gptr_lane, uint32_t lds_byte_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds_byte_off) : "memory", "m0");
+}
+template <int VM>
+__device__ __forceinline__ void ring_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+}
+__device__ __forceinline__ void wave_fft_fwd_s(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
+    wave_sync();
+    fwds_seg1(lane, z, xb, T1);
+    wave_sync();
+    fwds_seg2_ld(lane, z, xb);
+    fwds_seg2_st(lane, z, xb, w);
+    wave_sync();
+    fwds_seg3(lane, z, xb);
+}
+__device__ __forceinline__ void wave_fft_inv_s(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
+    wave_sync();
+    invs_seg1(lane, z, xb, w);
+    wave_sync();
+    invs_seg2_ld(lane, z, xb);
+    invs_seg2_st(lane, z, xb);
+    wave_sync();
+    invs_seg3(lane, z, xb, T1);
+}
+
 #endif
 
 }  // namespace thfhe

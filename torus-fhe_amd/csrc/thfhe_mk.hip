@@ -29,32 +29,6 @@ using namespace thfhe;
 
 namespace {
 
-__device__ __forceinline__ void mk_ring_dma(const cplx *gptr_lane, uint32_t lds_byte_off) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds_byte_off) : "memory", "m0");
-}
-template <int VM>
-__device__ __forceinline__ void mk_ring_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
-}
-__device__ __forceinline__ void mk_fft_fwd(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
-    wave_sync();
-    fwds_seg1(lane, z, xb, T1);
-    wave_sync();
-    fwds_seg2_ld(lane, z, xb);
-    fwds_seg2_st(lane, z, xb, w);
-    wave_sync();
-    fwds_seg3(lane, z, xb);
-}
-__device__ __forceinline__ void mk_fft_inv(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
-    wave_sync();
-    invs_seg1(lane, z, xb, w);
-    wave_sync();
-    invs_seg2_ld(lane, z, xb);
-    invs_seg2_st(lane, z, xb);
-    wave_sync();
-    invs_seg3(lane, z, xb, T1);
-}
-
 // ------------------------------------------------------------------------------------------------------
 // key transform: one wave per (pi, row, output) key polynomial, four limb spectra each
 // ------------------------------------------------------------------------------------------------------
@@ -78,7 +52,7 @@ __global__ __launch_bounds__(256) void mk_key_transform_kernel(const int64_t *__
     key_limbs64_to_z(lane, poly, z);
 #pragma unroll
     for (int h = 0; h < 4; h++) {
-        mk_fft_fwd(lane, z[h], sX[wave], sT1, w64);
+        wave_fft_fwd_s(lane, z[h], sX[wave], sT1, w64);
         cplx *dst = spec + mk_chunk_index(pi, r, h, o, rows) * 512;
 #pragma unroll
         for (int m = 0; m < 8; m++) dst[m * 64 + lane] = cplx{z[h][m].re * (1.0 / 512), z[h][m].im * (1.0 / 512)};
@@ -165,7 +139,7 @@ __device__ __forceinline__ void mk_blind_rotate_role(const MKBRArgs &a, cplx *sT
     int slot_issue = 0;
     const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sRing[0][0] + (uint32_t)wave * 1024u;
     auto issue = [&]() {
-        mk_ring_dma(gsrc, ring_base + (uint32_t)slot_issue * 8192u);
+        ring_dma(gsrc, ring_base + (uint32_t)slot_issue * 8192u);
         if (q_issue + 1 < total_chunks) {
             gsrc += 512;
             q_issue++;
@@ -194,24 +168,24 @@ __device__ __forceinline__ void mk_blind_rotate_role(const MKBRArgs &a, cplx *sT
             if (active) {
                 if (r % L == 0) load_rotated16_hi(lane, acc + (r / L) * 1024, a2n, offset, t);
                 digits_to_z(t, (r % L) + 1, Bgbit, z);
-                mk_fft_fwd(lane, z, xb, sT1, w64);
+                wave_fft_fwd_s(lane, z, xb, sT1, w64);
             }
 #pragma unroll
             for (int s = 0; s < 8; s++) {  // chunk (limb h = s >> 1, output s & 1)
-                if (s == 0) mk_ring_barrier<2>(); else mk_ring_barrier<1>();
+                if (s == 0) ring_barrier<2>(); else ring_barrier<1>();
                 if (s > 0) issue();
                 if (active && (s & 1) == o) mac8(lane, S[s >> 1], z, &sRing[slot_use][0]);
                 slot_use = slot_use == 2 ? 0 : slot_use + 1;
             }
-            mk_ring_barrier<2>();
+            ring_barrier<2>();
             issue();
         }
         if (active) {
 #pragma unroll
-            for (int h = 0; h < 4; h++) mk_fft_inv(lane, S[h], xb, sT1, w64);
+            for (int h = 0; h < 4; h++) wave_fft_inv_s(lane, S[h], xb, sT1, w64);
             acc_update16_64(lane, acc + o * 1024, S);
         }
-        mk_ring_barrier<3>();  // both output waves have updated acc before anybody rotates it again
+        ring_barrier<3>();  // both output waves have updated acc before anybody rotates it again
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -192,32 +192,6 @@ __global__ __launch_bounds__(256, 2) void sk_blind_rotate_kernel(BRArgs a) {
 // three chunks are in flight under every forward transform.  Per row: 5 barriers, 4 DMA issues per wave.
 // A wave whose mod-switched mask word is 0 (J/bootstrap.jl:40) or that has no job still streams and synchronises.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ring_dma(const cplx *gptr_lane, uint32_t lds_byte_off) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds_byte_off) : "memory", "m0");
-}
-template <int VM>
-__device__ __forceinline__ void ring_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
-}
-__device__ __forceinline__ void wave_fft_fwd_s(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
-    wave_sync();
-    fwds_seg1(lane, z, xb, T1);
-    wave_sync();
-    fwds_seg2_ld(lane, z, xb);
-    fwds_seg2_st(lane, z, xb, w);
-    wave_sync();
-    fwds_seg3(lane, z, xb);
-}
-__device__ __forceinline__ void wave_fft_inv_s(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
-    wave_sync();
-    invs_seg1(lane, z, xb, w);
-    wave_sync();
-    invs_seg2_ld(lane, z, xb);
-    invs_seg2_st(lane, z, xb);
-    wave_sync();
-    invs_seg3(lane, z, xb, T1);
-}
-
 template <int L>
 __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) {
     __shared__ cplx sT1[512];

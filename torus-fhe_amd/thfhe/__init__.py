@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libthfhe_hip.so")
+LIB_PATH = os.environ.get("THFHE_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libthfhe_hip.so"))
 
 # gate opcodes (include/thfhe_hip.h enum thfhe_gate)
 NAND, OR, AND, XOR, XNOR, NOR, ANDNY, ANDYN, ORNY, ORYN, MUX, NOT, COPY, AND3 = range(14)
