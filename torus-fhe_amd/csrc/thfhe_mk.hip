@@ -206,6 +206,76 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_ring_kernel(MKBRArgs a
 }
 
 // ------------------------------------------------------------------------------------------------------
+// blind rotate + extract, cooperative variant (the default): one 512-thread workgroup = ONE gate.  The eight (output, limb)
+// spectra of a 3-gen external product map onto the eight waves:
+//   phase 1  waves 0 .. 2l-1: wave r rotates / decomposes / transforms digit row r and publishes the spectrum in LDS;
+//            then every wave requests its key chunks (2l x 8 loads of 16 B per lane, into registers);
+//   phase 2  all waves, (o, h) = (wave >> 2, wave & 3): S = sum_r spectrum_r * key(r, h, o); inverse transform;
+//            round(S) << 16h is added into accumulator polynomial o with 64-bit LDS atomics (integer adds commute: bit-exact).
+// Two workgroup barriers per CMux (the ring kernel needs 9 per digit row) and no redundant forward transforms: measured
+// 1.3x the ring kernel's throughput at 1024 gates and 3.5x lower latency for a handful of gates.
+// LDS: T1 8 + acc 16 + spectra 2l x 8 + 8 transpose buffers x 8 KiB (l = 3: 136 KiB).
+// ------------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a) {
+    constexpr int ROWS = 2 * L;
+    __shared__ cplx sT1[512];
+    __shared__ int64_t sAcc[2048];
+    __shared__ cplx sSpec[ROWS][512];
+    __shared__ cplx sX[8][512];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    sT1[threadIdx.x] = a.tw[threadIdx.x];
+    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)], a.tw[512 + 2 * 8 + (lane & 7)], a.tw[512 + 4 * 8 + (lane & 7)]};
+    const long job = blockIdx.x;
+    const int32_t *bara = a.bara + job * a.w_pad;
+    const int Bgbit = a.Bgbit;
+    const uint64_t offset = decomp_offset64(L, Bgbit);
+    if (wave == 0) acc_init16_64(lane, sAcc, sAcc + 1024, a.barb[job], a.mu);
+    __syncthreads();
+    const int o = wave >> 2, h = wave & 3;
+    unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc) + o * 1024;
+
+    for (int i = 0; i < a.pn; i++) {  // party-major, key index inner: J/3gen_mk_internals.jl:66-84
+        const int ai = bara[i];       // uniform over the workgroup
+        if (ai == 0) continue;
+        const int a2n = ai & 2047;
+        if (wave < ROWS) {
+            uint32_t t[16];
+            cplx z[8];
+            load_rotated16_hi(lane, sAcc + (wave / L) * 1024, a2n, offset, t);
+            digits_to_z(t, (wave % L) + 1, Bgbit, z);
+            wave_fft_fwd_s(lane, z, sX[wave], sT1, w64);
+#pragma unroll
+            for (int m = 0; m < 8; m++) sSpec[wave][m * 64 + lane] = z[m];
+        }
+        cplx B[ROWS][8];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) load8(lane, B[r], a.bk + mk_chunk_index(i, r, h, o, ROWS) * 512);
+        __syncthreads();  // spectra published; every rotated read of the accumulator is done
+        cplx S[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) S[m] = cplx{0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            cplx z[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) z[m] = sSpec[r][m * 64 + lane];
+            mac8r(S, z, B[r]);
+        }
+        wave_fft_inv_s(lane, S, sX[wave], sT1, w64);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int q = lane + 64 * m;
+            atomicAdd(accu + q, (unsigned long long)round_i64(S[m].re) << (16 * h));
+            atomicAdd(accu + q + 512, (unsigned long long)round_i64(S[m].im) << (16 * h));
+        }
+        __syncthreads();  // accumulator updated before anybody rotates it again
+    }
+    if (wave == 0) extract16_64(lane, sAcc, sAcc + 1024, a.out + job * 1025);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // key switch: one workgroup per gate, parties in sequence          J/mk_internals.jl:730-744
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mk_ksk_pad_kernel(const int32_t *__restrict__ src, long rows, int n, int row_words,
@@ -308,6 +378,7 @@ struct thfhe_mk_ctx {
     int32_t *d_ksk = nullptr;
     cplx *d_tw = nullptr;
     int row_words = 0, w_pad = 0, words = 0;
+    int coop_max_jobs = 1 << 30;  // cooperative kernel for batches up to this many rotations (measured: faster than the ring kernel at every size)
     size_t cap_jobs = 0;
     int32_t *d_bara = nullptr, *d_barb = nullptr, *d_u = nullptr, *d_tmp = nullptr;
     size_t cap_stage = 0;
@@ -359,14 +430,20 @@ int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1,
     hipLaunchKernelGGL(mk_prologue_kernel, pg, dim3(256), 0, c->stream, d0, d1, d2, L0, L1, rot, c->words, c->w_pad, (long)jobs, c->d_bara, c->d_barb);
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[1], c->stream));
     MKBRArgs a{c->d_bk, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)jobs, c->p.parties * c->p.n, c->w_pad, c->p.Bgbit, mu};
-    const dim3 grid((unsigned)((jobs + 3) / 4)), block(512);
+    // THFHE_MK_VARIANT=3 / 4 force the ring / cooperative kernel; default: cooperative up to coop_max_jobs rotations
+    static const int variant = getenv("THFHE_MK_VARIANT") ? atoi(getenv("THFHE_MK_VARIANT")) : 0;
+    const bool coop = variant == 4 || (variant == 0 && jobs <= (size_t)c->coop_max_jobs);
+    const dim3 grid(coop ? (unsigned)jobs : (unsigned)((jobs + 3) / 4)), block(512);
+#define THFHE_MK_LAUNCH(LL)                                                                               \
+    case LL:                                                                                              \
+        if (coop) hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<LL>, grid, block, 0, c->stream, a);      \
+        else hipLaunchKernelGGL(mk_blind_rotate_ring_kernel<LL>, grid, block, 0, c->stream, a);           \
+        break;
     switch (c->p.l) {
-    case 1: hipLaunchKernelGGL(mk_blind_rotate_ring_kernel<1>, grid, block, 0, c->stream, a); break;
-    case 2: hipLaunchKernelGGL(mk_blind_rotate_ring_kernel<2>, grid, block, 0, c->stream, a); break;
-    case 3: hipLaunchKernelGGL(mk_blind_rotate_ring_kernel<3>, grid, block, 0, c->stream, a); break;
-    case 4: hipLaunchKernelGGL(mk_blind_rotate_ring_kernel<4>, grid, block, 0, c->stream, a); break;
+        THFHE_MK_LAUNCH(1) THFHE_MK_LAUNCH(2) THFHE_MK_LAUNCH(3) THFHE_MK_LAUNCH(4)
     default: return thfhe_fail(THFHE_E_UNSUPPORTED, "decomposition length l must be 1..4");
     }
+#undef THFHE_MK_LAUNCH
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[2], c->stream));
     MKKSArgs k{c->d_ksk, c->d_u, d_dst, (long)jobs, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words};
     hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)jobs), dim3(256), 0, c->stream, k);
