@@ -284,9 +284,9 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
 // idle; here the work of one CMux is spread over the eight waves:
 //   phase 1  waves 0 .. 2l-1: wave r rotates/decomposes/transforms digit row r and publishes its spectrum in LDS;
 //            meanwhile waves 0..3 already have their key chunks (row r, column c, limb h) in flight (2l x 8 loads);
-//   phase 2  waves 0..3 = (column c, limb h): S = sum_r spectrum_r * key(r, c, h), inverse transform;
-//            the hi-limb wave hands round(hi) to the lo-limb wave of its column, which updates the accumulator.
-// Three workgroup barriers per CMux.  LDS: T1 8 + acc 8 + spectra 2l x 8 + 8 transpose buffers x 8 + hi-limb 8 KiB.
+//   phase 2  waves 4..7 = (column c, limb h): S = sum_r spectrum_r * key(r, c, h), inverse transform, accumulate.
+// Two workgroup barriers per CMux; limbs are added into the accumulator with 32-bit LDS atomics.
+// LDS: T1 8 + acc 8 + spectra 2l x 8 + 8 transpose buffers x 8 KiB.
 // ------------------------------------------------------------------------------------------------------
 // two independent forward transforms interleaved segment by segment (two transpose buffers): the LDS round trips of one
 // overlap the butterflies of the other when the wave is alone on its SIMD
@@ -311,7 +311,6 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
     __shared__ int32_t sAcc[2048];
     __shared__ cplx sSpec[ROWS][512];
     __shared__ cplx sX[8][512];
-    __shared__ uint32_t sHi[2][1024];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     sT1[threadIdx.x] = a.tw[threadIdx.x];
@@ -349,8 +348,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
 #pragma unroll
                 for (int m = 0; m < 8; m++) sSpec[wave][m * 64 + lane] = za[m];
             }
-            __syncthreads();  // spectra published
-            __syncthreads();  // (multiply / inverse phase of waves 4..7)
+            __syncthreads();  // spectra published; waves 4..7 multiply, inverse-transform and update the accumulator
         } else {
             // key chunks of this wave's (c, h) for every row: in flight while waves 0..3 transform
             cplx B[ROWS][8];
@@ -368,22 +366,14 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
                 mac8r(S, z, B[r]);
             }
             wave_fft_inv_s(lane, S, sX[wave], sT1, w64);
-            if (h == 1) {
+            // acc[c] += round(limb) << 16h with 32-bit LDS atomics: the lo and hi waves of a column add independently
+            // (integer adds commute, so the result is bit-exact); every rotated read happened before the barrier above
+            unsigned int *ap = reinterpret_cast<unsigned int *>(sAcc) + c * 1024;
 #pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    sHi[c][lane + 64 * m] = round_lo32(S[m].re);
-                    sHi[c][lane + 64 * m + 512] = round_lo32(S[m].im);
-                }
-            }
-            __syncthreads();  // hi limbs published
-            if (h == 0) {
-                int32_t *ap = sAcc + c * 1024;
-#pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    const int q = lane + 64 * m;
-                    ap[q] = (int32_t)((uint32_t)ap[q] + round_lo32(S[m].re) + (sHi[c][q] << 16));
-                    ap[q + 512] = (int32_t)((uint32_t)ap[q + 512] + round_lo32(S[m].im) + (sHi[c][q + 512] << 16));
-                }
+            for (int m = 0; m < 8; m++) {
+                const int q = lane + 64 * m;
+                atomicAdd(ap + q, round_lo32(S[m].re) << (16 * h));
+                atomicAdd(ap + q + 512, round_lo32(S[m].im) << (16 * h));
             }
         }
         __syncthreads();  // accumulator updated before anybody rotates it again
