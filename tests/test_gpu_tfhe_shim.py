@@ -52,3 +52,47 @@ def test_boots_symbols_on_libtfhe_structs(O):
     assert np.array_equal(T.read_samples(sr, br), orc.gates(O.XOR, ca, cb))
     L.thfhe_tfhe_forget_key.restype = None
     L.thfhe_tfhe_forget_key(ck)
+
+
+def test_concurrent_boots_calls_are_batched_and_correct(O):
+    """Eight host threads call bootsXOR / bootsAND / bootsMUX concurrently on a shared key set (the reference's OpenMP pattern,
+    src/KNN_medical_data.cpp:681-691); the shim's combining batcher evaluates queued calls together; results stay bit-exact."""
+    import threading
+    import thfhe
+    import tfhe_structs as T
+    L = thfhe.lib()
+    p = O.make_params("SK-128", n=40)
+    K = O.SKKeys(p, 32, 2.0**-25, 2.0**-15)
+    orc = O.Oracle(p, K.bk, K.ksk)
+    img = T.TfheKeyImage(p, K.bk, K.ksk)
+    ck = C.byref(img.cloud)
+    G = 24
+    rng = np.random.default_rng(3)
+    a, b, c = (rng.integers(0, 2, G) for _ in range(3))
+    ca, cb, cc = (K.encrypt_bits(v, 2.0**-15, 40 + q) for q, v in enumerate((a, b, c)))
+    sa, ba = T.make_samples(ca); sb, bb = T.make_samples(cb); sc, bc = T.make_samples(cc); sr, br = T.make_samples(np.zeros_like(ca))
+    ops = [O.XOR, O.AND, O.MUX]
+    names = {O.XOR: "bootsXOR", O.AND: "bootsAND", O.MUX: "bootsMUX"}
+    for nm in names.values():
+        getattr(L, nm).restype = None
+    SZ = C.sizeof(T.LweSample)
+
+    def worker(tid):
+        for g in range(tid, G, 8):
+            op = ops[g % 3]
+            f = getattr(L, names[op])
+            if op == O.MUX:
+                f(C.byref(sr, g * SZ), C.byref(sa, g * SZ), C.byref(sb, g * SZ), C.byref(sc, g * SZ), ck)
+            else:
+                f(C.byref(sr, g * SZ), C.byref(sa, g * SZ), C.byref(sb, g * SZ), ck)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    got = T.read_samples(sr, br)
+    for op in ops:
+        idx = [g for g in range(G) if ops[g % 3] == op]
+        ref = orc.gates(op, ca[idx], cb[idx], cc[idx] if op == O.MUX else None)
+        assert np.array_equal(got[idx], ref), names[op]
+    L.thfhe_tfhe_forget_key.restype = None
+    L.thfhe_tfhe_forget_key(ck)

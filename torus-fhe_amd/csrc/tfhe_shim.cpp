@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstddef>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -79,9 +80,8 @@ Entry get_ctx(const TFheGateBootstrappingCloudKeySet *bk) {
     return e;
 }
 
-void run(int op, LweSample *result, const LweSample *ca, const LweSample *cb, const LweSample *cc, int count,
-         const TFheGateBootstrappingCloudKeySet *bk) {
-    const Entry e = get_ctx(bk);
+// One evaluation of `count` gates of one kind on contiguous LweSample arrays.
+void run_batch(const Entry &e, int op, LweSample *result, const LweSample *ca, const LweSample *cb, const LweSample *cc, int count) {
     const size_t rec = (size_t)e.n + 1;
     std::vector<int32_t> buf(4 * rec * count);
     int32_t *x = buf.data(), *y = x + rec * count, *z = y + rec * count, *o = z + rec * count;
@@ -102,13 +102,106 @@ void run(int op, LweSample *result, const LweSample *ca, const LweSample *cb, co
     }
 }
 
+// ---- combining batcher for the single-gate entry points --------------------------------------------------------------
+// The reference calls boots* from an OpenMP loop on a shared key set (src/KNN_medical_data.cpp:681-691).  Calls that arrive
+// while a launch is in flight are queued and evaluated TOGETHER by the next leader thread in one mixed-opcode launch
+// (thfhe_gates_mixed; MUX requests in one thfhe_gates call), so T concurrent callers cost one gate latency, not T.
+struct Request {
+    int op;
+    LweSample *result;
+    const LweSample *a, *b, *c;
+    bool done = false;
+};
+struct Batcher {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<Request *> queue;
+    bool leader_active = false;
+};
+std::mutex g_bmu;
+std::map<const TFheGateBootstrappingCloudKeySet *, Batcher *> g_batchers;
+
+Batcher *get_batcher(const TFheGateBootstrappingCloudKeySet *bk) {
+    std::lock_guard<std::mutex> g(g_bmu);
+    auto it = g_batchers.find(bk);
+    if (it != g_batchers.end()) return it->second;
+    return g_batchers[bk] = new Batcher;
+}
+
+void execute(const Entry &e, const std::vector<Request *> &batch) {
+    const size_t rec = (size_t)e.n + 1;
+    std::vector<Request *> two, mux;
+    for (Request *r : batch) (r->op == THFHE_MUX ? mux : two).push_back(r);
+    auto pack1 = [&](int32_t *dst, const LweSample *s) {
+        for (int q = 0; q < e.n; q++) dst[q] = s->a[q];
+        dst[e.n] = s->b;
+    };
+    auto unpack1 = [&](LweSample *dst, const int32_t *src) {
+        for (int q = 0; q < e.n; q++) dst->a[q] = src[q];
+        dst->b = src[e.n];
+        dst->current_variance = 0.0;
+    };
+    if (!two.empty()) {
+        const size_t cnt = two.size();
+        std::vector<int32_t> buf(3 * rec * cnt), ops(cnt);
+        int32_t *x = buf.data(), *y = x + rec * cnt, *o = y + rec * cnt;
+        for (size_t g = 0; g < cnt; g++) {
+            ops[g] = two[g]->op;
+            pack1(x + g * rec, two[g]->a);
+            pack1(y + g * rec, two[g]->b);
+        }
+        if (thfhe_gates_mixed(e.ctx, ops.data(), x, y, o, cnt) != THFHE_OK) die("gate evaluation failed");
+        for (size_t g = 0; g < cnt; g++) unpack1(two[g]->result, o + g * rec);
+    }
+    if (!mux.empty()) {
+        const size_t cnt = mux.size();
+        std::vector<int32_t> buf(4 * rec * cnt);
+        int32_t *x = buf.data(), *y = x + rec * cnt, *z = y + rec * cnt, *o = z + rec * cnt;
+        for (size_t g = 0; g < cnt; g++) {
+            pack1(x + g * rec, mux[g]->a);
+            pack1(y + g * rec, mux[g]->b);
+            pack1(z + g * rec, mux[g]->c);
+        }
+        if (thfhe_gates(e.ctx, THFHE_MUX, x, y, z, o, cnt) != THFHE_OK) die("gate evaluation failed");
+        for (size_t g = 0; g < cnt; g++) unpack1(mux[g]->result, o + g * rec);
+    }
+}
+
+void run_one(int op, LweSample *result, const LweSample *ca, const LweSample *cb, const LweSample *cc, const TFheGateBootstrappingCloudKeySet *bk) {
+    const Entry e = get_ctx(bk);
+    Batcher *B = get_batcher(bk);
+    Request r{op, result, ca, cb, cc};
+    std::unique_lock<std::mutex> lk(B->m);
+    B->queue.push_back(&r);
+    while (!r.done) {
+        if (!B->leader_active) {
+            B->leader_active = true;
+            std::vector<Request *> batch;
+            batch.swap(B->queue);
+            lk.unlock();
+            if (!batch.empty()) execute(e, batch);
+            lk.lock();
+            for (Request *q : batch) q->done = true;
+            B->leader_active = false;
+            B->cv.notify_all();
+        } else {
+            B->cv.wait(lk);
+        }
+    }
+}
+
+void run(int op, LweSample *result, const LweSample *ca, const LweSample *cb, const LweSample *cc, int count,
+         const TFheGateBootstrappingCloudKeySet *bk) {
+    run_batch(get_ctx(bk), op, result, ca, cb, cc, count);
+}
+
 }  // namespace
 
 extern "C" {
 
 #define THFHE_GATE2(NAME, OP)                                                                                                   \
     void NAME(LweSample *result, const LweSample *ca, const LweSample *cb, const TFheGateBootstrappingCloudKeySet *bk) {        \
-        run(OP, result, ca, cb, nullptr, 1, bk);                                                                                \
+        run_one(OP, result, ca, cb, nullptr, bk);                                                                                \
     }
 THFHE_GATE2(bootsNAND, THFHE_NAND)
 THFHE_GATE2(bootsOR, THFHE_OR)
@@ -123,7 +216,7 @@ THFHE_GATE2(bootsORYN, THFHE_ORYN)
 #undef THFHE_GATE2
 
 void bootsMUX(LweSample *result, const LweSample *a, const LweSample *b, const LweSample *c, const TFheGateBootstrappingCloudKeySet *bk) {
-    run(THFHE_MUX, result, a, b, c, 1, bk);
+    run_one(THFHE_MUX, result, a, b, c, bk);
 }
 void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
     const int n = bk->params->in_out_params->n;  // not bootstrapped: plain negation (J/gates.jl:76-79)
