@@ -293,56 +293,58 @@ struct MKKSArgs {
     int n, t, basebit, parties, row_words;
 };
 
-__global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a) {
+// grid = (gates, parties, nsplit): block (g, p, s) key-switches coordinates [s*1024/nsplit, (s+1)*1024/nsplit) of gate g with
+// party p's key and adds its partial sum into the zero-initialised output with integer atomics (order-independent: bit-exact)
+__global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a, int nsplit) {
     __shared__ uint32_t sA[1024];
     __shared__ uint32_t sRed[4][768];
-    __shared__ uint32_t sB;
     const long g = blockIdx.x;
+    const int p = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t prec_offset = 1u << (32 - (1 + a.basebit * a.t));
     const int32_t *u = a.u + (size_t)g * 1025;
-    for (int q = tid; q < 1024; q += 256) sA[q] = (uint32_t)u[q] + prec_offset;
-    if (tid == 0) sB = (uint32_t)u[1024];
+    const int i_lo = (int)blockIdx.z * (1024 / nsplit), i_hi = i_lo + 1024 / nsplit;
+    for (int q = i_lo + tid; q < i_hi; q += 256) sA[q] = (uint32_t)u[q] + prec_offset;
     __syncthreads();
     const int base1 = (1 << a.basebit) - 1;
     const uint32_t mask = (uint32_t)base1;
     const int wpl = a.row_words / 64;  // words per lane (<= 12)
-    int32_t *out = a.out + (size_t)g * ((size_t)a.parties * a.n + 1);
-    for (int p = 0; p < a.parties; p++) {
-        uint32_t r[12];
+    unsigned int *out = reinterpret_cast<unsigned int *>(a.out) + (size_t)g * ((size_t)a.parties * a.n + 1);
+    uint32_t r[12];
 #pragma unroll
-        for (int q = 0; q < 12; q++) r[q] = 0;
-        const int32_t *kp = a.ksk + (size_t)p * 1024 * a.t * base1 * a.row_words;
-        for (int i = wave; i < 1024; i += 4) {
-            const uint32_t ai = sA[i];
-            for (int j = 0; j < a.t; j++) {
-                const uint32_t d = (ai >> (32 - (j + 1) * a.basebit)) & mask;
-                if (d == 0) continue;
-                const int32_t *row = kp + (((size_t)i * a.t + j) * base1 + (d - 1)) * a.row_words + 2 * lane;
+    for (int q = 0; q < 12; q++) r[q] = 0;
+    const int32_t *kp = a.ksk + (size_t)p * 1024 * a.t * base1 * a.row_words;
+    for (int i = i_lo + wave; i < i_hi; i += 4) {
+        const uint32_t ai = sA[i];
+        for (int j = 0; j < a.t; j++) {
+            const uint32_t d = (ai >> (32 - (j + 1) * a.basebit)) & mask;
+            if (d == 0) continue;
+            const int32_t *row = kp + (((size_t)i * a.t + j) * base1 + (d - 1)) * a.row_words + 2 * lane;
 #pragma unroll
-                for (int q = 0; q < 6; q++)
-                    if (2 * q < wpl) {
-                        const uint2 x = *reinterpret_cast<const uint2 *>(row + q * 128);
-                        r[2 * q] -= x.x;
-                        r[2 * q + 1] -= x.y;
-                    }
-            }
+            for (int q = 0; q < 6; q++)
+                if (2 * q < wpl) {
+                    const uint2 x = *reinterpret_cast<const uint2 *>(row + q * 128);
+                    r[2 * q] -= x.x;
+                    r[2 * q + 1] -= x.y;
+                }
         }
-#pragma unroll
-        for (int q = 0; q < 6; q++)
-            if (2 * q < wpl) {
-                sRed[wave][q * 128 + 2 * lane] = r[2 * q];
-                sRed[wave][q * 128 + 2 * lane + 1] = r[2 * q + 1];
-            }
-        __syncthreads();
-        for (int q = tid; q <= a.n; q += 256) {
-            const uint32_t v = sRed[0][q] + sRed[1][q] + sRed[2][q] + sRed[3][q];
-            if (q < a.n) out[(size_t)p * a.n + q] = (int32_t)v;
-            else atomicAdd(&sB, v);
-        }
-        __syncthreads();
     }
-    if (tid == 0) out[(size_t)a.parties * a.n] = (int32_t)sB;
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+        if (2 * q < wpl) {
+            sRed[wave][q * 128 + 2 * lane] = r[2 * q];
+            sRed[wave][q * 128 + 2 * lane + 1] = r[2 * q + 1];
+        }
+    __syncthreads();
+    for (int q = tid; q <= a.n; q += 256) {
+        uint32_t v = sRed[0][q] + sRed[1][q] + sRed[2][q] + sRed[3][q];
+        if (q < a.n) {
+            atomicAdd(out + (size_t)p * a.n + q, v);
+        } else {
+            if (p == 0 && blockIdx.z == 0) v += (uint32_t)u[1024];  // b = b' + sum over parties of the parts' b
+            atomicAdd(out + (size_t)a.parties * a.n, v);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void mk_linear_kernel(const int32_t *__restrict__ x, const int32_t *__restrict__ y, int32_t *__restrict__ out,
@@ -446,7 +448,9 @@ int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1,
 #undef THFHE_MK_LAUNCH
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[2], c->stream));
     MKKSArgs k{c->d_ksk, c->d_u, d_dst, (long)jobs, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words};
-    hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)jobs), dim3(256), 0, c->stream, k);
+    const int nsplit = jobs * c->p.parties <= 64 ? 16 : (jobs * c->p.parties <= 256 ? 4 : 1);  // fill the chip at small batch sizes
+    THFHE_HIP(hipMemsetAsync(d_dst, 0, jobs * ((size_t)c->words + 1) * sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)jobs, (unsigned)c->p.parties, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
     if (c->profiling) {
         THFHE_HIP(hipEventRecord(c->ev[3], c->stream));
         c->ev_valid = true;
