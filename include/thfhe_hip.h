@@ -116,6 +116,8 @@ int thfhe_mk_ctx_create(const thfhe_params *params, const int64_t *bk_coeff, con
 void thfhe_mk_ctx_destroy(thfhe_mk_ctx *ctx);
 int thfhe_mk_gates(thfhe_mk_ctx *ctx, int op, const int32_t *in0, const int32_t *in1, const int32_t *in2,
                    int32_t *out, size_t count);
+/* one launch for a DAG level of two-input 3-gen gates (NAND / OR / AND / XOR), per-gate opcodes in the HOST array ops */
+int thfhe_mk_gates_mixed(thfhe_mk_ctx *ctx, const int32_t *ops, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count);
 int thfhe_mk_bootstrap(thfhe_mk_ctx *ctx, int64_t mu, const int32_t *x, int32_t *out, size_t count);
 void *thfhe_mk_dev_alloc(thfhe_mk_ctx *ctx, size_t bytes);
 void thfhe_mk_dev_free(thfhe_mk_ctx *ctx, void *p);

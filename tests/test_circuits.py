@@ -91,3 +91,42 @@ def test_distance_circuit_on_reference_ciphertexts(O, sk128):
         c = vals[[cir.gates[g][3] for g in gs]] if op == thfhe.MUX else None
         assert np.array_equal(vals[cir.n_inputs + np.array(gs)], orc.gates(op, a, b, c))
     ck.close()
+
+
+def test_mk_integer_circuits_plaintext():
+    from thfhe import circuits as Cc
+    cir = Cc.Circuit()
+    a, b = cir.inputs(8), cir.inputs(8)
+    zero, one = cir.inputs(2)
+    s = Cc.mk_add_3gen(cir, a, b, zero)
+    d = Cc.mk_sub_3gen(cir, a, b, one)
+    lt = Cc.mk_less_3gen(cir, a, b, one)
+    lsb = lambda v: [(v >> i) & 1 for i in range(8)]
+    val = lambda w, v: sum(int(v[x]) << i for i, x in enumerate(w))
+    for x, y in [(3, 9), (10, 10), (7, 1), (100, 27), (1, 2)]:
+        v = Cc.simulate(cir, lsb(x) + lsb(y) + [0, 1])
+        assert val(s, v) == (x + y) % 256 and val(d, v) == (x - y) % 256 and bool(v[lt]) == (((x - y) % 256) >= 128)
+
+
+@pytest.mark.gpu
+def test_mk_adder_demo_on_gpu(O):
+    """The reference's multi-key demo (3-gen-mk-tfhe/multikey_3gen.jl:66-92): two parties, 8-bit encrypted integers,
+    mk_add_3gen_v2 -- as one levelised DAG on the GPU (thfhe_mk_gates_mixed)."""
+    import thfhe
+    from thfhe import circuits as Cc
+    p = O.make_params("MK2")
+    sg = O.SIGMAS["MK2"]
+    K = O.MKKeys(p, 0x5EED0001, sg["bk"], sg["ks"])
+    ck = thfhe.MKCloudKey(thfhe.make_params("MK2"), K.bk, K.ksk, device=0)
+    cir = Cc.Circuit()
+    a, b = cir.inputs(8), cir.inputs(8)
+    zero = cir.inputs(1)[0]
+    s = Cc.mk_add_3gen(cir, a, b, zero)
+    rng = np.random.default_rng(9)
+    for trial in range(3):
+        m1, m2 = int(rng.integers(1, 11)), int(rng.integers(1, 11))
+        bits = [(m1 >> i) & 1 for i in range(8)] + [(m2 >> i) & 1 for i in range(8)] + [0]
+        vals = Cc.evaluate(ck, cir, K.encrypt_bits(bits, sg["lwe"], 60 + trial))
+        out = K.decrypt_bits(vals[s])
+        assert sum(int(x) << i for i, x in enumerate(out)) == m1 + m2
+    ck.close()

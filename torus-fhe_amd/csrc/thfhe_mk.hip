@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void mk_key_transform_kernel(const int64_t *__
 struct MKLin {
     int32_t cb, cx, cy, cz;
 };
-inline bool mk_gate_lin(int op, int which, MKLin &L) {
+__host__ __device__ inline bool mk_gate_lin(int op, int which, MKLin &L) {
     const int32_t E8 = 1 << 29, E4 = 1 << 30;
     switch (op) {
     case THFHE_NAND: L = MKLin{E8, -1, -1, 0}; return true;   // J/3gen_mk_gates.jl:8-14
@@ -79,14 +79,15 @@ inline bool mk_gate_lin(int op, int which, MKLin &L) {
     }
 }
 __global__ __launch_bounds__(256) void mk_prologue_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ in1,
-                                                           const int32_t *__restrict__ in2, MKLin L0, MKLin L1, int rot_per_gate,
-                                                           int words, int w_pad, long jobs, int32_t *__restrict__ bara,
+                                                           const int32_t *__restrict__ in2, MKLin L0, MKLin L1, const int32_t *__restrict__ ops,
+                                                           int rot_per_gate, int words, int w_pad, long jobs, int32_t *__restrict__ bara,
                                                            int32_t *__restrict__ barb) {
     const long job = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (job >= jobs || i > words) return;
     const long gate = job / rot_per_gate;
-    const MKLin L = (job % rot_per_gate) == 0 ? L0 : L1;
+    MKLin L = (job % rot_per_gate) == 0 ? L0 : L1;
+    if (ops) mk_gate_lin(ops[gate], 0, L);  // per-gate opcodes of a mixed DAG level (validated on the host)
     const size_t off = (size_t)gate * (words + 1) + i;
     uint32_t v = (uint32_t)L.cx * (uint32_t)in0[off];
     if (L.cy != 0) v += (uint32_t)L.cy * (uint32_t)in1[off];
@@ -425,11 +426,11 @@ int mk_ensure_stage(thfhe_mk_ctx *c, size_t words) {
 
 // bootstrap (prologue + blind rotate + key switch) of `jobs` = gates * rot jobs; results to d_dst[jobs][P*n+1]
 int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1, const int32_t *d2, MKLin L0, MKLin L1, int rot,
-                          size_t gates, int64_t mu, int32_t *d_dst) {
+                          size_t gates, int64_t mu, int32_t *d_dst, const int32_t *d_ops = nullptr) {
     const size_t jobs = gates * rot;
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[0], c->stream));
     dim3 pg((unsigned)((c->words + 1 + 255) / 256), (unsigned)jobs);
-    hipLaunchKernelGGL(mk_prologue_kernel, pg, dim3(256), 0, c->stream, d0, d1, d2, L0, L1, rot, c->words, c->w_pad, (long)jobs, c->d_bara, c->d_barb);
+    hipLaunchKernelGGL(mk_prologue_kernel, pg, dim3(256), 0, c->stream, d0, d1, d2, L0, L1, d_ops, rot, c->words, c->w_pad, (long)jobs, c->d_bara, c->d_barb);
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[1], c->stream));
     MKBRArgs a{c->d_bk, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)jobs, c->p.parties * c->p.n, c->w_pad, c->p.Bgbit, mu};
     // THFHE_MK_VARIANT=3 / 4 force the ring / cooperative kernel; default: cooperative up to coop_max_jobs rotations
@@ -645,6 +646,31 @@ int thfhe_mk_gates(thfhe_mk_ctx *c, int op, const int32_t *in0, const int32_t *i
     for (int q = 0; q < 3; q++)
         if (src[q]) THFHE_HIP(hipMemcpyAsync(c->d_in[q], src[q], bytes, hipMemcpyHostToDevice, c->stream));
     rc = mk_gates_dev_locked(c, op, c->d_in[0], in1 ? c->d_in[1] : nullptr, in2 ? c->d_in[2] : nullptr, c->d_out, count);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+int thfhe_mk_gates_mixed(thfhe_mk_ctx *c, const int32_t *ops, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count) {
+    if (!c || !ops || !in0 || !in1 || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    for (size_t g = 0; g < count; g++)
+        if (!(ops[g] == THFHE_NAND || ops[g] == THFHE_OR || ops[g] == THFHE_AND || ops[g] == THFHE_XOR))
+            return thfhe_fail(THFHE_E_INVALID, "thfhe_mk_gates_mixed takes the two-input 3-gen gates NAND / OR / AND / XOR only");
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t words = count * ((size_t)c->words + 1), bytes = words * sizeof(int32_t);
+    int rc = mk_ensure_stage(c, words);
+    if (rc) return rc;
+    rc = mk_ensure_workspace(c, count);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(c->d_in[0], in0, bytes, hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_in[1], in1, bytes, hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_in[2], ops, count * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    MKLin L;
+    mk_gate_lin(THFHE_NAND, 0, L);
+    rc = mk_enqueue_bootstraps(c, c->d_in[0], c->d_in[1], nullptr, L, L, 1, count, (int64_t)1 << 61, c->d_out, c->d_in[2]);
     if (rc) return rc;
     THFHE_HIP(hipMemcpyAsync(out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     THFHE_HIP(hipStreamSynchronize(c->stream));

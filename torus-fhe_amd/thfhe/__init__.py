@@ -82,6 +82,7 @@ SIGNATURES = {
     "thfhe_mk_ctx_create": (C.c_int, [C.POINTER(Params), _i64p, _i32p, C.c_int, C.POINTER(_vp)]),
     "thfhe_mk_ctx_destroy": (None, [_vp]),
     "thfhe_mk_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
+    "thfhe_mk_gates_mixed": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_bootstrap": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_dev_alloc": (_vp, [_vp, C.c_size_t]),
     "thfhe_mk_dev_free": (None, [_vp, _vp]),
@@ -325,6 +326,14 @@ class MKCloudKey:
         z = _rec(z, self.words) if z is not None else None
         out = np.empty_like(x)
         _check(lib().thfhe_mk_gates(self.h, op, _p32(x), _p32(y), _p32(z), _p32(out), x.shape[0]))
+        return out
+
+    def gates_mixed(self, ops, x, y):
+        """One launch for a DAG level of two-input 3-gen gates with per-gate opcodes."""
+        x, y = _rec(x, self.words), _rec(y, self.words)
+        ops = np.ascontiguousarray(ops, np.int32)
+        out = np.empty_like(x)
+        _check(lib().thfhe_mk_gates_mixed(self.h, _p32(ops), _p32(x), _p32(y), _p32(out), x.shape[0]))
         return out
 
     def bootstrap(self, x, mu=MU8_64):

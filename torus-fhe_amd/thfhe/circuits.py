@@ -101,6 +101,34 @@ def distance_bw_data(cir, row_a, row_b, all_zero, all_one, lsb_one, zero):
     return result
 
 
+# ---- the reference's multi-key integer circuits (3gen_mk_gates.jl; bit vectors LSB-first, mk_api.jl:563-576) ----------
+def mk_add_3gen(cir, a, b, cin):
+    """mk_add_3gen / mk_add_3gen_v2, 3gen_mk_gates.jl:183-220."""
+    out = []
+    for i in range(len(a)):
+        t1 = cir.gate(XOR, a[i], b[i])
+        t2 = cir.gate(AND, a[i], b[i])
+        out.append(cir.gate(XOR, t1, cin))
+        t3 = cir.gate(AND, t1, cin)
+        cin = cir.gate(OR, t2, t3)
+    return out
+
+
+def mk_inv_3gen(cir, a, one):
+    """:223-233."""
+    return [cir.gate(XOR, x, one) for x in a]
+
+
+def mk_sub_3gen(cir, a, b, one):
+    """a - b = a + ~b + 1, :236-244."""
+    return mk_add_3gen(cir, a, mk_inv_3gen(cir, b, one), one)
+
+
+def mk_less_3gen(cir, a, b, one):
+    """sign bit of a - b, :247-255."""
+    return mk_sub_3gen(cir, a, b, one)[-1]
+
+
 def simulate(cir, input_bits):
     """Plaintext evaluation of the DAG (wiring check): bool[n_inputs] -> bool[n_wires]."""
     from . import ANDNY, ANDYN, NAND, NOR, ORNY, ORYN, XNOR
