@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build the native pieces in-tree when they are missing or stale (hipcc cross-compiles gfx950 without a GPU)."""
+    import subprocess
+    lib = os.path.join(ROOT, "torus-fhe_amd", "lib", "libthfhe_hip.so")
+    csrc = os.path.join(ROOT, "torus-fhe_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
+        if os.path.exists("/opt/rocm/bin/hipcc"):
+            subprocess.run(["make", "-s", "-C", csrc], check=True)
+
+
 @pytest.fixture(scope="session")
 def O():
     import oracle_lib
