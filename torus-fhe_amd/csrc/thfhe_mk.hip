@@ -175,7 +175,7 @@ __device__ __forceinline__ void mk_blind_rotate_role(const MKBRArgs &a, cplx *sT
             for (int s = 0; s < 8; s++) {  // chunk (limb h = s >> 1, output s & 1)
                 if (s == 0) ring_barrier<2>(); else ring_barrier<1>();
                 if (s > 0) issue();
-                if (active && (s & 1) == o) mac8(lane, S[s >> 1], z, &sRing[slot_use][0]);
+                if (active && (s & 1) == o) mac8_lean(lane, S[s >> 1], z, &sRing[slot_use][0]);
                 slot_use = slot_use == 2 ? 0 : slot_use + 1;
             }
             ring_barrier<2>();

@@ -159,10 +159,10 @@ __global__ __launch_bounds__(256, 2) void sk_blind_rotate_kernel(BRArgs a) {
                 digits_to_z(t, p, Bgbit, z);
                 wave_fft_fwd(lane, z, xb, sT1, sT2);
                 const cplx *B = a.bk + bk_spec_index(i, j * L + (p - 1), 0, 0, 2 * L);
-                mac8(lane, S[0][0], z, B);
-                mac8(lane, S[0][1], z, B + 512);
-                mac8(lane, S[1][0], z, B + 1024);
-                mac8(lane, S[1][1], z, B + 1536);
+                mac8_lean(lane, S[0][0], z, B);
+                mac8_lean(lane, S[0][1], z, B + 512);
+                mac8_lean(lane, S[1][0], z, B + 1024);
+                mac8_lean(lane, S[1][1], z, B + 1536);
             }
         }
         wave_sync();  // every rotated read of acc precedes the updates below
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
                 // publish chunk: own slice landed (c4 == 0: two younger DMAs in flight, else one), then everybody
                 if (c4 == 0) ring_barrier<2>(); else ring_barrier<1>();
                 if (c4 > 0) issue();  // the slot of the chunk consumed before this barrier is free
-                if (active) mac8(lane, S[c4 >> 1][c4 & 1], z, &sRing[slot_use][0]);
+                if (active) mac8_lean(lane, S[c4 >> 1][c4 & 1], z, &sRing[slot_use][0]);
                 slot_use = slot_use == 2 ? 0 : slot_use + 1;
             }
             ring_barrier<2>();  // the row's last chunk is consumed by all: refill its slot before the next transform
