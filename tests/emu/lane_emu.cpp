@@ -34,7 +34,7 @@ struct WaveS {  // the LDS-ring kernel's variant: swizzled 512-slot buffer, pass
     W64 w[64];
     WaveS() {
         make_twiddles_1024(T1, T2);
-        for (int l = 0; l < 64; l++) w[l] = W64{T2[1 * 8 + (l & 7)], T2[2 * 8 + (l & 7)], T2[4 * 8 + (l & 7)]};
+        for (int l = 0; l < 64; l++) w[l] = W64{T2[1 * 8 + (l & 7)]};
     }
     void fwd(cplx (*z)[8]) {
         for (int l = 0; l < 64; l++) fwds_seg1(l, z[l], xbuf, T1);

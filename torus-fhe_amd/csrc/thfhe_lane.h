@@ -170,18 +170,18 @@ THFHE_FN int ys_b(int j1, int lane) { return (lane >> 3) * 64 + ((j1 * 8 + (lane
 THFHE_FN int ys_c(int k1, int lane) { return (lane >> 3) * 64 + ((k1 * 8 + ((lane & 7) ^ k1)) ^ (((lane >> 4) & 1) << 3)); }
 THFHE_FN int ys_d(int j0, int lane) { return (lane >> 3) * 64 + (((lane & 7) * 8 + (j0 ^ (lane & 7))) ^ (((lane >> 4) & 1) << 3)); }
 
-struct W64 {  // per-lane powers of w = omega_64^(lane & 7)
-    cplx w1, w2, w4;
+struct W64 {  // per-lane root w = omega_64^(lane & 7); its powers are rebuilt in every pass-2 twiddle step (registers are scarcer than FP64 ops)
+    cplx w1;
 };
 THFHE_FN void w64_powers(const W64 &w, cplx (&p)[8]) {
     p[0] = cplx{1.0, 0.0};
     p[1] = w.w1;
-    p[2] = w.w2;
-    p[3] = cmul(w.w1, w.w2);
-    p[4] = w.w4;
-    p[5] = cmul(w.w1, w.w4);
-    p[6] = cmul(w.w2, w.w4);
-    p[7] = cmul(p[3], w.w4);
+    p[2] = cmul(w.w1, w.w1);
+    p[3] = cmul(p[2], w.w1);
+    p[4] = cmul(p[2], p[2]);
+    p[5] = cmul(p[4], w.w1);
+    p[6] = cmul(p[4], p[2]);
+    p[7] = cmul(p[4], p[3]);
 }
 
 THFHE_FN void fwds_seg1(int lane, cplx (&z)[8], cplx *xbuf, const cplx *T1) {

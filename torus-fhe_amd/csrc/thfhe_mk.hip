@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void mk_key_transform_kernel(const int64_t *__
     for (int t = threadIdx.x; t < 512; t += 256) sT1[t] = tw[t];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const W64 w64{tw[512 + 1 * 8 + (lane & 7)], tw[512 + 2 * 8 + (lane & 7)], tw[512 + 4 * 8 + (lane & 7)]};
+    const W64 w64{tw[512 + 1 * 8 + (lane & 7)]};
     const int rows = 2 * l;
     const long item = (long)blockIdx.x * 4 + wave;  // (pi, r, o)
     if (item >= PN * rows * 2) return;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void mk_blind_rotate_role(const MKBRArgs &a, cplx *sT
     constexpr int ROWS = 2 * L;
     constexpr int o = O;
     const int g = wave & 3;   // gate within the workgroup
-    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)], a.tw[512 + 2 * 8 + (lane & 7)], a.tw[512 + 4 * 8 + (lane & 7)]};
+    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
     const long job = (long)blockIdx.x * 4 + g;
     const bool has_job = job < a.jobs;
     int64_t *acc = sAcc[g];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     sT1[threadIdx.x] = a.tw[threadIdx.x];
-    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)], a.tw[512 + 2 * 8 + (lane & 7)], a.tw[512 + 4 * 8 + (lane & 7)]};
+    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
     const long job = blockIdx.x;
     const int32_t *bara = a.bara + job * a.w_pad;
     const int Bgbit = a.Bgbit;

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     sT1[threadIdx.x] = a.tw[threadIdx.x];
-    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)], a.tw[512 + 2 * 8 + (lane & 7)], a.tw[512 + 4 * 8 + (lane & 7)]};
+    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
     const long job = (long)blockIdx.x * 8 + wave;
     const bool has_job = job < a.jobs;
     int32_t *acc = sAcc[wave];
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     sT1[threadIdx.x] = a.tw[threadIdx.x];
-    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)], a.tw[512 + 2 * 8 + (lane & 7)], a.tw[512 + 4 * 8 + (lane & 7)]};
+    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
     const long job = blockIdx.x;
     const int32_t *bara = a.bara + job * a.n_pad;
     const int Bgbit = a.Bgbit;
