@@ -10,9 +10,7 @@
 //   mk_key_transform_kernel   TransformedBootstrapKeyPart_3gen (J/3gen_mk_internals.jl:45-56): int64 coefficient
 //                             polynomials -> four balanced 16-bit limbs -> FP64 spectra in streaming order
 //   mk_prologue_kernel        gate linear part + mod-switch of the (n, P) mask matrix and of b
-//   mk_blind_rotate_ring_kernel   one 512-thread workgroup = 4 gates x 2 waves (one wave per output polynomial
-//                             c1' / c0'), key streamed once per CU through the 3 x 8 KiB LDS ring (same machinery
-//                             as sk_blind_rotate_ring_kernel); all 160 KiB of LDS
+//   mk_blind_rotate_coop_kernel   one 512-thread workgroup per gate: the eight (output polynomial, limb) spectra on eight waves
 //   mk_keyswitch_kernel       P key switches of the extracted sample + the cross-party combine of b
 #include <hip/hip_runtime.h>
 
@@ -115,106 +113,16 @@ struct MKBRArgs {
     int64_t mu;
 };
 
-// The role o (output polynomial: 0 = c1' mask, 1 = c0' body) is a template parameter so that each role's code keeps its four
-// limb spectra in fixed registers; waves w and w+4 of a workgroup take roles 0 and 1 of gate w & 3 and share a SIMD, so exactly
-// one of them multiplies at every chunk step.
-template <int L, int O>
-__device__ __forceinline__ void mk_blind_rotate_role(const MKBRArgs &a, cplx *sT1, int64_t (*sAcc)[2048], cplx (*sX)[512], cplx (*sRing)[512],
-                                                     int wave, int lane) {
-    constexpr int ROWS = 2 * L;
-    constexpr int o = O;
-    const int g = wave & 3;   // gate within the workgroup
-    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
-    const long job = (long)blockIdx.x * 4 + g;
-    const bool has_job = job < a.jobs;
-    int64_t *acc = sAcc[g];
-    cplx *xb = sX[wave];
-    const int32_t *bara = a.bara + (has_job ? job : 0) * a.w_pad;
-    const int Bgbit = a.Bgbit;
-    const uint64_t offset = decomp_offset64(L, Bgbit);
-    if (has_job && o == 0) acc_init16_64(lane, acc, acc + 1024, a.barb[job], a.mu);
-
-    const long total_chunks = (long)a.pn * ROWS * 8;
-    const cplx *gsrc = a.bk + wave * 64 + lane;
-    long q_issue = 0;
-    int slot_issue = 0;
-    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sRing[0][0] + (uint32_t)wave * 1024u;
-    auto issue = [&]() {
-        ring_dma(gsrc, ring_base + (uint32_t)slot_issue * 8192u);
-        if (q_issue + 1 < total_chunks) {
-            gsrc += 512;
-            q_issue++;
-        }
-        slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
-    };
-    __syncthreads();
-    issue();
-    issue();
-    issue();
-    int slot_use = 0;
-
-    for (int i = 0; i < a.pn; i++) {  // party-major, key index inner: J/3gen_mk_internals.jl:66-84
-        const int ai = bara[i];
-        const bool active = has_job && ai != 0;
-        const int a2n = ai & 2047;
-        cplx S[4][8];
-#pragma unroll
-        for (int h = 0; h < 4; h++)
-#pragma unroll
-            for (int m = 0; m < 8; m++) S[h][m] = cplx{0.0, 0.0};
-        uint32_t t[16];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            cplx z[8];
-            if (active) {
-                if (r % L == 0) load_rotated16_hi(lane, acc + (r / L) * 1024, a2n, offset, t);
-                digits_to_z(t, (r % L) + 1, Bgbit, z);
-                wave_fft_fwd_s(lane, z, xb, sT1, w64);
-            }
-#pragma unroll
-            for (int s = 0; s < 8; s++) {  // chunk (limb h = s >> 1, output s & 1)
-                if (s == 0) ring_barrier<2>(); else ring_barrier<1>();
-                if (s > 0) issue();
-                if (active && (s & 1) == o) mac8_lean(lane, S[s >> 1], z, &sRing[slot_use][0]);
-                slot_use = slot_use == 2 ? 0 : slot_use + 1;
-            }
-            ring_barrier<2>();
-            issue();
-        }
-        if (active) {
-#pragma unroll
-            for (int h = 0; h < 4; h++) wave_fft_inv_s(lane, S[h], xb, sT1, w64);
-            acc_update16_64(lane, acc + o * 1024, S);
-        }
-        ring_barrier<3>();  // both output waves have updated acc before anybody rotates it again
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (has_job && o == 0) extract16_64(lane, acc, acc + 1024, a.out + job * 1025);
-}
-
-template <int L>
-__global__ __launch_bounds__(512, 2) void mk_blind_rotate_ring_kernel(MKBRArgs a) {
-    __shared__ cplx sT1[512];
-    __shared__ int64_t sAcc[4][2048];
-    __shared__ cplx sX[8][512];
-    __shared__ cplx sRing[3][512];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    sT1[threadIdx.x] = a.tw[threadIdx.x];
-    if (wave < 4) mk_blind_rotate_role<L, 0>(a, sT1, sAcc, sX, sRing, wave, lane);
-    else mk_blind_rotate_role<L, 1>(a, sT1, sAcc, sX, sRing, wave, lane);
-}
-
 // ------------------------------------------------------------------------------------------------------
-// blind rotate + extract, cooperative variant (the default): one 512-thread workgroup = ONE gate.  The eight (output, limb)
+// blind rotate + extract: one 512-thread workgroup = ONE gate.  The eight (output, limb)
 // spectra of a 3-gen external product map onto the eight waves:
 //   phase 1  waves 0 .. 2l-1: wave r rotates / decomposes / transforms digit row r and publishes the spectrum in LDS;
 //            then every wave requests its key chunks (2l x 8 loads of 16 B per lane, into registers);
 //   phase 2  all waves, (o, h) = (wave >> 2, wave & 3): S = sum_r spectrum_r * key(r, h, o); inverse transform;
 //            round(S) << 16h is added into accumulator polynomial o with 64-bit LDS atomics (integer adds commute: bit-exact).
-// Two workgroup barriers per CMux (the ring kernel needs 9 per digit row) and no redundant forward transforms: measured
-// 1.3x the ring kernel's throughput at 1024 gates and 3.5x lower latency for a handful of gates.
+// Two workgroup barriers per CMux and no redundant forward transforms.  (An LDS-ring variant in the style of
+// sk_blind_rotate_ring_kernel -- 4 gates x 2 output waves per workgroup -- was built and measured 1.3x slower at 1024 gates
+// and 3.5x slower for a handful: 9 barriers per digit row, redundant forward transforms; see git history / DESIGN.md 4.3.)
 // LDS: T1 8 + acc 16 + spectra 2l x 8 + 8 transpose buffers x 8 KiB (l = 3: 136 KiB).
 // ------------------------------------------------------------------------------------------------------
 template <int L>
@@ -381,7 +289,6 @@ struct thfhe_mk_ctx {
     int32_t *d_ksk = nullptr;
     cplx *d_tw = nullptr;
     int row_words = 0, w_pad = 0, words = 0;
-    int coop_max_jobs = 1 << 30;  // cooperative kernel for batches up to this many rotations (measured: faster than the ring kernel at every size)
     size_t cap_jobs = 0;
     int32_t *d_bara = nullptr, *d_barb = nullptr, *d_u = nullptr, *d_tmp = nullptr;
     size_t cap_stage = 0;
@@ -433,20 +340,14 @@ int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1,
     hipLaunchKernelGGL(mk_prologue_kernel, pg, dim3(256), 0, c->stream, d0, d1, d2, L0, L1, d_ops, rot, c->words, c->w_pad, (long)jobs, c->d_bara, c->d_barb);
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[1], c->stream));
     MKBRArgs a{c->d_bk, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)jobs, c->p.parties * c->p.n, c->w_pad, c->p.Bgbit, mu};
-    // THFHE_MK_VARIANT=3 / 4 force the ring / cooperative kernel; default: cooperative up to coop_max_jobs rotations
-    static const int variant = getenv("THFHE_MK_VARIANT") ? atoi(getenv("THFHE_MK_VARIANT")) : 0;
-    const bool coop = variant == 4 || (variant == 0 && jobs <= (size_t)c->coop_max_jobs);
-    const dim3 grid(coop ? (unsigned)jobs : (unsigned)((jobs + 3) / 4)), block(512);
-#define THFHE_MK_LAUNCH(LL)                                                                               \
-    case LL:                                                                                              \
-        if (coop) hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<LL>, grid, block, 0, c->stream, a);      \
-        else hipLaunchKernelGGL(mk_blind_rotate_ring_kernel<LL>, grid, block, 0, c->stream, a);           \
-        break;
+    const dim3 grid((unsigned)jobs), block(512);
     switch (c->p.l) {
-        THFHE_MK_LAUNCH(1) THFHE_MK_LAUNCH(2) THFHE_MK_LAUNCH(3) THFHE_MK_LAUNCH(4)
+    case 1: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<1>, grid, block, 0, c->stream, a); break;
+    case 2: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<2>, grid, block, 0, c->stream, a); break;
+    case 3: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<3>, grid, block, 0, c->stream, a); break;
+    case 4: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<4>, grid, block, 0, c->stream, a); break;
     default: return thfhe_fail(THFHE_E_UNSUPPORTED, "decomposition length l must be 1..4");
     }
-#undef THFHE_MK_LAUNCH
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[2], c->stream));
     MKKSArgs k{c->d_ksk, c->d_u, d_dst, (long)jobs, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words};
     const int nsplit = jobs * c->p.parties <= 64 ? 16 : (jobs * c->p.parties <= 256 ? 4 : 1);  // fill the chip at small batch sizes
