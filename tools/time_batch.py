@@ -1,4 +1,4 @@
-"""Developer timing: one NAND batch of a given size (env THFHE_BR_VARIANT=1 selects the first-generation kernel)."""
+"""Developer timing: one NAND batch of a given size."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,5 +16,5 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
     for rep in range(3):
         ck.gates_dev(thfhe.NAND, da, db, None, do, B); ck.sync()
         t = ck.last_timings()
-    print(f"variant={os.environ.get('THFHE_BR_VARIANT','3')} batch {B}: blind_rotate {t['blind_rotate_ms']:.3f} ms keyswitch {t['keyswitch_ms']:.3f} ms total {t['total_ms']:.3f} ms -> {B/t['total_ms']*1e3:.0f} gates/s", flush=True)
+    print(f"batch {B}: blind_rotate {t['blind_rotate_ms']:.3f} ms keyswitch {t['keyswitch_ms']:.3f} ms total {t['total_ms']:.3f} ms -> {B/t['total_ms']*1e3:.0f} gates/s", flush=True)
     for d in (da, db, do): d.free()

@@ -5,8 +5,9 @@
 //                             rows -> two-limb FP64 spectra in the blind-rotate kernel's register order
 //   sk_prologue_kernel        gate linear part (J/gates.jl:15-177) + mod-switch decode_message(.,2N)
 //                             (J/bootstrap.jl:80-81) -> bara[job][n], barb[job]
-//   sk_blind_rotate_kernel    blind_rotate_and_extract (J/bootstrap.jl:38-65): one wavefront per job, accumulator in
-//                             LDS for all n CMuxes, key spectra streamed with 16-B/lane coalesced loads
+//   sk_blind_rotate_ring_kernel / sk_blind_rotate_coop_kernel   blind_rotate_and_extract (J/bootstrap.jl:38-65): accumulator in
+//                             LDS for all n CMuxes; throughput (8 gates per workgroup, key through an LDS-DMA ring) and latency
+//                             (one workgroup per gate) variants
 //   sk_keyswitch_kernel       keyswitch (J/keyswitch.jl:45-80) (+ the MUX combine of J/gates.jl:172-176)
 //   sk_linear_kernel          NOT / COPY (J/gates.jl:76-79)
 #include <hip/hip_runtime.h>
@@ -100,10 +101,7 @@ __global__ __launch_bounds__(256) void sk_prologue_kernel(const int32_t *__restr
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// blind rotate + extract, first generation (kept for A/B: THFHE_BR_VARIANT=1).  4 waves per workgroup, each wave one job
-// with its own key loads; 78 848 B LDS -> 2 workgroups per CU.  Bound by the CU's vector-memory path (profiles/r01_summary.md).
-// ------------------------------------------------------------------------------------------------------
+// arguments of the blind-rotate kernels
 struct BRArgs {
     const cplx *bk;        // spectral key
     const cplx *tw;        // T1[512] ++ T2[64]
@@ -115,77 +113,16 @@ struct BRArgs {
     int32_t mu;
 };
 
-template <int L>
-__global__ __launch_bounds__(256, 2) void sk_blind_rotate_kernel(BRArgs a) {
-    __shared__ cplx sT1[512];
-    __shared__ cplx sT2[64];
-    __shared__ int32_t sAcc[4][2048];
-    __shared__ cplx sX[4][kXbufSlots];
-    for (int t = threadIdx.x; t < 512; t += 256) sT1[t] = a.tw[t];
-    if (threadIdx.x < 64) sT2[threadIdx.x] = a.tw[512 + threadIdx.x];
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const long job = (long)blockIdx.x * 4 + wave;
-    if (job >= a.jobs) return;
-    int32_t *acc = sAcc[wave];
-    cplx *xb = sX[wave];
-    const int32_t *bara = a.bara + job * a.n_pad;
-    const int Bgbit = a.Bgbit;
-    const uint32_t offset = decomp_offset32(L, Bgbit);
-
-    acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
-    wave_sync();
-
-    for (int i = 0; i < a.n; i++) {
-        const int ai = bara[i];  // wave-uniform
-        if (ai == 0) continue;   // J/bootstrap.jl:40
-        const int a2n = ai & 2047;
-        cplx S[2][2][8];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
-
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            uint32_t t[16];
-            load_rotated16(lane, acc + j * 1024, a2n, offset, t);
-#pragma unroll
-            for (int p = 1; p <= L; p++) {
-                cplx z[8];
-                digits_to_z(t, p, Bgbit, z);
-                wave_fft_fwd(lane, z, xb, sT1, sT2);
-                const cplx *B = a.bk + bk_spec_index(i, j * L + (p - 1), 0, 0, 2 * L);
-                mac8_lean(lane, S[0][0], z, B);
-                mac8_lean(lane, S[0][1], z, B + 512);
-                mac8_lean(lane, S[1][0], z, B + 1024);
-                mac8_lean(lane, S[1][1], z, B + 1536);
-            }
-        }
-        wave_sync();  // every rotated read of acc precedes the updates below
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            wave_fft_inv(lane, S[c][0], xb, sT1, sT2);
-            wave_fft_inv(lane, S[c][1], xb, sT1, sT2);
-            acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
-        }
-        wave_sync();
-    }
-    extract16(lane, acc, acc + 1024, a.out + job * 1025);
-}
-
 // ------------------------------------------------------------------------------------------------------
-// blind rotate + extract, variant 3 ("LDS ring"): the shipping kernel.
+// blind rotate + extract, throughput kernel ("LDS ring").
 //
 // One 512-thread workgroup = 8 wavefronts = 8 jobs, one workgroup per CU, all 160 KiB of LDS:
 //     T1 twiddles 8 KiB | 8 x (accumulator 8 KiB + transpose buffer 8 KiB) | key ring 3 x 8 KiB        = 163 840 B
 // The eight waves walk the key index i, the digit rows and the four (column, limb) chunks of a row in lock step.
 // A chunk is 8 KiB of key spectrum = 8 slices of 1 KiB; wave w brings slice w into the ring with ONE
 // global_load_lds_dwordx4 (LDS-DMA, no registers), so the whole key crosses the CU's vector-memory path once per
-// workgroup instead of once per wave (variant 1 was bound by exactly that path: profiles/r01_summary.md).
+// workgroup instead of once per wave (the first-generation kernel -- one wave per job with its own key loads, git history --
+// was bound by exactly that path: profiles/r01_summary.md).
 // Hand-off of chunk q: every wave waits for its own slice (s_waitcnt vmcnt(N), N = younger DMAs in flight), then
 // s_barrier -- after it the chunk is complete AND everybody has finished reading chunk q-1, whose slot is refilled
 // at once with chunk q+2.  One extra barrier after a row's last chunk frees that slot before the next transform, so
@@ -550,12 +487,8 @@ int ensure_stage(thfhe_ctx *c, size_t words) {
 
 template <int L>
 void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
-    // THFHE_BR_VARIANT=1 selects the first-generation kernel (one wave per job, per-wave key loads) for A/B measurements;
-    // =3 / =4 force the ring / cooperative kernel.  Default: cooperative (latency) kernel for small batches, ring otherwise.
-    static const int variant = getenv("THFHE_BR_VARIANT") ? atoi(getenv("THFHE_BR_VARIANT")) : 0;
-    if (variant == 1)
-        hipLaunchKernelGGL(sk_blind_rotate_kernel<L>, dim3((unsigned)((a.jobs + 3) / 4)), dim3(256), 0, s, a);
-    else if (variant == 4 || (variant == 0 && a.jobs <= coop_max))
+    // small batches: cooperative latency kernel (one workgroup per gate); large ones: LDS-ring kernel (eight gates per workgroup)
+    if (a.jobs <= coop_max)
         hipLaunchKernelGGL(sk_blind_rotate_coop_kernel<L>, dim3((unsigned)a.jobs), dim3(512), 0, s, a);
     else
         hipLaunchKernelGGL(sk_blind_rotate_ring_kernel<L>, dim3((unsigned)((a.jobs + 7) / 8)), dim3(512), 0, s, a);
