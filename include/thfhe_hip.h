@@ -100,7 +100,7 @@ int thfhe_gates_dev(thfhe_ctx *ctx, int op, const int32_t *d_in0, const int32_t 
 int thfhe_sync(thfhe_ctx *ctx);
 
 /* Batches of at most `max_jobs` rotations run on the cooperative latency kernel (one workgroup per gate), larger ones on
- * the LDS-ring throughput kernel (eight gates per workgroup).  0 forces the ring kernel.  Default 768 (measured crossover on MI355X is ~1000). */
+ * the LDS-ring throughput kernel (eight gates per workgroup).  0 forces the ring kernel.  Default 1024 (measured crossover on MI355X is ~1150). */
 int thfhe_set_coop_threshold(thfhe_ctx *ctx, int max_jobs);
 
 /* Per-kernel device timing: when enabled, every *_dev call brackets each kernel with HIP events on the

@@ -70,7 +70,7 @@ def test_every_blind_rotate_kernel_bit_exact(O, sk128, gpu128):
         gpu128.set_coop_threshold(1 << 20)
         assert np.array_equal(gpu128.gates(thfhe.XOR, ca, cb), ref)          # cooperative kernel
     finally:
-        gpu128.set_coop_threshold(768)
+        gpu128.set_coop_threshold(1024)
 
 
 def test_mux_bit_exact(O, sk128, gpu128):

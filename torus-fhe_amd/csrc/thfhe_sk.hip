@@ -216,31 +216,16 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// blind rotate + extract, latency variant ("cooperative"): one 512-thread workgroup = ONE job.  For the small batches
-// the reference's gate-at-a-time callers produce (boots* shims, ripple-carry circuits) the ring kernel leaves 7/8 of a CU
-// idle; here the work of one CMux is spread over the eight waves:
-//   phase 1  waves 0 .. 2l-1: wave r rotates/decomposes/transforms digit row r and publishes its spectrum in LDS;
-//            meanwhile waves 0..3 already have their key chunks (row r, column c, limb h) in flight (2l x 8 loads);
-//   phase 2  waves 4..7 = (column c, limb h): S = sum_r spectrum_r * key(r, c, h), inverse transform, accumulate.
-// Two workgroup barriers per CMux; limbs are added into the accumulator with 32-bit LDS atomics.
-// LDS: T1 8 + acc 8 + spectra 2l x 8 + 8 transpose buffers x 8 KiB.
+// blind rotate + extract, latency kernel ("cooperative"): one 512-thread workgroup = ONE job.  For the small batches the
+// reference's gate-at-a-time callers produce (boots* shims, ripple-carry circuits) the ring kernel leaves 7/8 of a CU idle;
+// here the work of one CMux is spread over the eight waves:
+//   phase 1  waves 0 .. 2l-1: wave r rotates / decomposes / transforms digit row r and publishes its spectrum in LDS;
+//            every wave has already requested the key chunks of its phase-2 role (l rows x 8 loads of 16 B per lane);
+//   phase 2  wave w = (column c, limb h, half): S = sum over its half of the rows of spectrum_r * key(r, c, h); inverse
+//            transform of this PARTIAL sum (the inverse is linear and every partial sum is an exact integer polynomial);
+//            round(S) << 16h is added into accumulator polynomial c with 32-bit LDS atomics (integer adds commute).
+// Two workgroup barriers per CMux; each key byte is fetched once per CU.  LDS: T1 8 + acc 8 + spectra 2l x 8 + 8 x 8 KiB.
 // ------------------------------------------------------------------------------------------------------
-// two independent forward transforms interleaved segment by segment (two transpose buffers): the LDS round trips of one
-// overlap the butterflies of the other when the wave is alone on its SIMD
-__device__ __forceinline__ void wave_fft_fwd_s2(int lane, cplx (&za)[8], cplx (&zb)[8], cplx *xa, cplx *xbb, const cplx *T1, const W64 &w) {
-    wave_sync();
-    fwds_seg1(lane, za, xa, T1);
-    fwds_seg1(lane, zb, xbb, T1);
-    wave_sync();
-    fwds_seg2_ld(lane, za, xa);
-    fwds_seg2_ld(lane, zb, xbb);
-    fwds_seg2_st(lane, za, xa, w);
-    fwds_seg2_st(lane, zb, xbb, w);
-    wave_sync();
-    fwds_seg3(lane, za, xa);
-    fwds_seg3(lane, zb, xbb);
-}
-
 template <int L>
 __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) {
     constexpr int ROWS = 2 * L;
@@ -258,60 +243,42 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
     const uint32_t offset = decomp_offset32(L, Bgbit);
     if (wave == 0) acc_init16(lane, sAcc, sAcc + 1024, a.barb[job], a.mu);
     __syncthreads();
-    // roles: waves 0..3 transform digit rows (wave w: row w, and row w+4 if it exists); waves 4..7 = (column c, limb h)
-    const int c = (wave >> 1) & 1, h = wave & 1;
+    const int c = (wave >> 2) & 1, h = (wave >> 1) & 1, r0 = (wave & 1) * L;  // phase-2 role: rows r0 .. r0+L-1
+    unsigned int *ap = reinterpret_cast<unsigned int *>(sAcc) + c * 1024;
 
     for (int i = 0; i < a.n; i++) {
         const int ai = bara[i];  // uniform over the workgroup
         if (ai == 0) continue;   // J/bootstrap.jl:40
         const int a2n = ai & 2047;
-        if (wave < 4) {
-            if (wave < ROWS) {
-                uint32_t t[16];
-                cplx za[8];
-                load_rotated16(lane, sAcc + (wave / L) * 1024, a2n, offset, t);
-                digits_to_z(t, (wave % L) + 1, Bgbit, za);
-                if (wave + 4 < ROWS) {
-                    cplx zb[8];
-                    const int r2 = wave + 4;
-                    if (r2 / L != wave / L) load_rotated16(lane, sAcc + (r2 / L) * 1024, a2n, offset, t);
-                    digits_to_z(t, (r2 % L) + 1, Bgbit, zb);
-                    wave_fft_fwd_s2(lane, za, zb, sX[wave], sX[wave + 4], sT1, w64);
+        cplx B[L][8];
 #pragma unroll
-                    for (int m = 0; m < 8; m++) sSpec[r2][m * 64 + lane] = zb[m];
-                } else {
-                    wave_fft_fwd_s(lane, za, sX[wave], sT1, w64);
-                }
+        for (int r = 0; r < L; r++) load8(lane, B[r], a.bk + bk_spec_index(i, r0 + r, c, h, ROWS));
+        if (wave < ROWS) {
+            uint32_t t[16];
+            cplx z[8];
+            load_rotated16(lane, sAcc + (wave / L) * 1024, a2n, offset, t);
+            digits_to_z(t, (wave % L) + 1, Bgbit, z);
+            wave_fft_fwd_s(lane, z, sX[wave], sT1, w64);
 #pragma unroll
-                for (int m = 0; m < 8; m++) sSpec[wave][m * 64 + lane] = za[m];
-            }
-            __syncthreads();  // spectra published; waves 4..7 multiply, inverse-transform and update the accumulator
-        } else {
-            // key chunks of this wave's (c, h) for every row: in flight while waves 0..3 transform
-            cplx B[ROWS][8];
+            for (int m = 0; m < 8; m++) sSpec[wave][m * 64 + lane] = z[m];
+        }
+        __syncthreads();  // spectra published; every rotated read of the accumulator is done
+        cplx S[8];
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) load8(lane, B[r], a.bk + bk_spec_index(i, r, c, h, ROWS));
-            __syncthreads();  // spectra published
-            cplx S[8];
+        for (int m = 0; m < 8; m++) S[m] = cplx{0.0, 0.0};
 #pragma unroll
-            for (int m = 0; m < 8; m++) S[m] = cplx{0.0, 0.0};
+        for (int r = 0; r < L; r++) {
+            cplx z[8];
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                cplx z[8];
+            for (int m = 0; m < 8; m++) z[m] = sSpec[r0 + r][m * 64 + lane];
+            mac8r(S, z, B[r]);
+        }
+        wave_fft_inv_s(lane, S, sX[wave], sT1, w64);
 #pragma unroll
-                for (int m = 0; m < 8; m++) z[m] = sSpec[r][m * 64 + lane];
-                mac8r(S, z, B[r]);
-            }
-            wave_fft_inv_s(lane, S, sX[wave], sT1, w64);
-            // acc[c] += round(limb) << 16h with 32-bit LDS atomics: the lo and hi waves of a column add independently
-            // (integer adds commute, so the result is bit-exact); every rotated read happened before the barrier above
-            unsigned int *ap = reinterpret_cast<unsigned int *>(sAcc) + c * 1024;
-#pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const int q = lane + 64 * m;
-                atomicAdd(ap + q, round_lo32(S[m].re) << (16 * h));
-                atomicAdd(ap + q + 512, round_lo32(S[m].im) << (16 * h));
-            }
+        for (int m = 0; m < 8; m++) {
+            const int q = lane + 64 * m;
+            atomicAdd(ap + q, round_lo32(S[m].re) << (16 * h));
+            atomicAdd(ap + q + 512, round_lo32(S[m].im) << (16 * h));
         }
         __syncthreads();  // accumulator updated before anybody rotates it again
     }
@@ -437,7 +404,7 @@ struct thfhe_ctx {
     cplx *d_bk = nullptr;     // spectral key
     int32_t *d_ksk = nullptr; // padded rows
     int ks_w = 0;             // words per lane of a padded KSK row
-    int coop_max_jobs = 768;  // batches up to this many rotations use the cooperative (latency) kernel (measured crossover ~1000)
+    int coop_max_jobs = 1024;  // batches up to this many rotations use the cooperative (latency) kernel (measured crossover ~1150)
     cplx *d_tw = nullptr;
     // workspace
     size_t cap_jobs = 0;
