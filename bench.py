@@ -134,7 +134,7 @@ def main():
     p = thfhe.make_params(args.set)
     mk = p.torus_bits == 64
     if mk:   # 3-gen multi-key (BASELINE.json configs[2], [4]); noise per J/mk_api.jl:32-38,84-90
-        lwe_sigma = {"MK2": 2.0**-13.52, "MK3": 2.0**-13.26, "MK4": 2.0**-13.26}.get(args.set, 2.0**-13.52)
+        lwe_sigma = {"MK2": 2.0**-13.52, "MK3": 2.0**-13.26, "MK4": 2.0**-13.26, "MK4-N2048": 2.0**-13.26}.get(args.set, 2.0**-13.52)
         K = keygen.MKSecretKeySet(p, seed=0x5EED0001, sigma_lwe=lwe_sigma, sigma_bk=2.0**-30.70)
         ck = thfhe.MKCloudKey(p, K.bk, K.ksk, device=device)
     else:    # SURVEY.md section 8(d) synthetic-input recipe
@@ -190,7 +190,7 @@ def main():
                                f"(P={p.parties}, n={p.n}, N={p.N}, k={p.k}, l={p.l}, Bgbit={p.Bgbit}, ks {p.ks_t}/{p.ks_basebit}), keys+ciphertexts resident in HBM",
                    "gates_per_gpu_per_step": B, "param_set": args.set, "parallelism": f"gate-batch sharding x{world}, replicated keys",
                    "timing_backend": backend},
-        "roofline": {"bound": "hbm", "kernel": f"{'mk' if mk else 'sk'}_blind_rotate_ring_kernel<{p.l}>",
+        "roofline": {"bound": "hbm", "kernel": (f"mk_blind_rotate_coop{'2k' if p.N == 2048 else ''}_kernel<{p.l}>" if mk else f"sk_blind_rotate_ring_kernel<{p.l}>"),
                      "achieved": br_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": br_achieved / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": br_bytes, "avg_launch_ms": br_avg_ms,
                      "note": "algorithmic bytes count the whole transformed key once per gate (SURVEY.md 8d); the kernel streams it once per "

@@ -119,6 +119,25 @@ int thfhe_mk_gates(thfhe_mk_ctx *ctx, int op, const int32_t *in0, const int32_t 
 /* one launch for a DAG level of two-input 3-gen gates (NAND / OR / AND / XOR), per-gate opcodes in the HOST array ops */
 int thfhe_mk_gates_mixed(thfhe_mk_ctx *ctx, const int32_t *ops, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count);
 int thfhe_mk_bootstrap(thfhe_mk_ctx *ctx, int64_t mu, const int32_t *x, int32_t *out, size_t count);
+/* Party-sharded building blocks (optional mode: one rank per party holds only that party's keys, i.e. a
+ * context created with parties = 1 from party p's key part).  All pointers are DEVICE pointers; calls enqueue on the context's
+ * stream.  The accumulator travels between ranks as int64[count][2][N] (mask polynomial, body polynomial).
+ *   prologue       : the gate's linear part (J/3gen_mk_gates.jl; op = -1: identity, i.e. plain mk_bootstrap_3gen of in0; which = 0 / 1
+ *                    selects the first / second AND of the 3-gen MUX) + mod-switch (J/numeric-functions.jl:70-73) of this party's n
+ *                    mask words [first_word, first_word + n) of records with rec_words = P_total*n + 1 words, and of b.
+ *   rotate_partial : run this context's n CMuxes (J/3gen_mk_internals.jl:66-74) on every accumulator.  d_bara = int32[count][n]
+ *                    mod-switched mask words of this party; d_acc_in == NULL starts from X^{-barb} * mu (first party).
+ *   extract        : rlwe_extract_sample_64 (J/rlwe.jl:70-74) -> int32[count][N+1]
+ *   keyswitch      : keyswitch of the extracted samples with this context's key(s) -> int32[count][P*n+1]      */
+int thfhe_mk_prologue_dev(thfhe_mk_ctx *ctx, int op, int which, const int32_t *d_in0, const int32_t *d_in1, const int32_t *d_in2,
+                          int rec_words, int first_word, int32_t *d_bara, int32_t *d_barb, size_t count);
+int thfhe_mk_rotate_partial_dev(thfhe_mk_ctx *ctx, const int32_t *d_bara, const int32_t *d_barb, int64_t mu,
+                                const int64_t *d_acc_in, int64_t *d_acc_out, size_t count);
+int thfhe_mk_extract_dev(thfhe_mk_ctx *ctx, const int64_t *d_acc, int32_t *d_u, size_t count);
+int thfhe_mk_keyswitch_dev(thfhe_mk_ctx *ctx, const int32_t *d_u, int32_t *d_out, size_t count);
+/* Enqueue every later call on the caller's HIP stream (e.g. the stream the caller's RCCL communicator synchronises with);
+ * NULL returns to the context's own stream.  Waits for work already enqueued. */
+int thfhe_mk_set_stream(thfhe_mk_ctx *ctx, void *hip_stream);
 void *thfhe_mk_dev_alloc(thfhe_mk_ctx *ctx, size_t bytes);
 void thfhe_mk_dev_free(thfhe_mk_ctx *ctx, void *p);
 int thfhe_mk_copy_h2d(thfhe_mk_ctx *ctx, void *dst, const void *src, size_t bytes);

@@ -269,3 +269,131 @@ void emu_mk_extract(const int64_t *acc, int32_t *out) {
     for (int ln = 0; ln < 64; ln++) extract16_64(ln, acc, acc + 1024, out);
 }
 }
+
+// ---- N = 2048: radix-2 split + two twisted 512-point transforms (thfhe_lane.h, "N = 2048" section) ---------------------------
+namespace {
+struct Wave2K {
+    cplx T1a[512], T1b[512], T2[64], scratch[512];
+    cplx xbuf[512];
+    W64 w[64];
+    Wave2K() {
+        make_twiddles_2048(T1a, T1b);
+        make_twiddles_1024(scratch, T2);
+        for (int l = 0; l < 64; l++) w[l] = W64{T2[1 * 8 + (l & 7)]};
+    }
+    template <int T>
+    void fwd(cplx (*z)[8]) {
+        const cplx *T1 = T == 1 ? T1a : T1b;
+        for (int l = 0; l < 64; l++) fwdt_seg1<T>(l, z[l], xbuf, T1);
+        for (int l = 0; l < 64; l++) fwds_seg2_ld(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) fwds_seg2_st(l, z[l], xbuf, w[l]);
+        for (int l = 0; l < 64; l++) fwds_seg3(l, z[l], xbuf);
+    }
+    template <int T>
+    void inv(cplx (*z)[8]) {
+        const cplx *T1 = T == 1 ? T1a : T1b;
+        for (int l = 0; l < 64; l++) invs_seg1(l, z[l], xbuf, w[l]);
+        for (int l = 0; l < 64; l++) invs_seg2_ld(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) invs_seg2_st(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) invt_seg3<T>(l, z[l], xbuf, T1);
+    }
+    // z16[lane][16] -> spectra y0[lane][8] (even outputs), y1[lane][8] (odd outputs)
+    void fwd2k(cplx (*z16)[16], cplx (*y0)[8], cplx (*y1)[8]) {
+        for (int l = 0; l < 64; l++) split2048(z16[l], y0[l], y1[l]);
+        fwd<1>(y0);
+        fwd<5>(y1);
+    }
+    void inv2k(cplx (*s0)[8], cplx (*s1)[8], cplx (*lo)[8], cplx (*hi)[8]) {  // returns 1024 * z
+        inv<1>(s0);
+        inv<5>(s1);
+        for (int l = 0; l < 64; l++) merge2048(s0[l], s1[l], lo[l], hi[l]);
+    }
+};
+}  // namespace
+
+extern "C" {
+// zin: 1024 complex in natural order j; out: [half][lane][m] complex; back: inverse of out, natural order, scaled by 1024
+void emu_fwd_raw_2k(const double *zin, double *out, double *back) {
+    Wave2K w;
+    static cplx z[64][16], y0[64][8], y1[64][8], lo[64][8], hi[64][8];
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 16; m++) z[l][m] = cplx{zin[2 * (l + 64 * m)], zin[2 * (l + 64 * m) + 1]};
+    w.fwd2k(z, y0, y1);
+    memcpy(out, y0, sizeof(y0));
+    memcpy(out + 64 * 8 * 2, y1, sizeof(y1));
+    w.inv2k(y0, y1, lo, hi);
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) {
+            back[2 * (l + 64 * m)] = lo[l][m].re;
+            back[2 * (l + 64 * m) + 1] = lo[l][m].im;
+            back[2 * (l + 64 * (m + 8))] = hi[l][m].re;
+            back[2 * (l + 64 * (m + 8)) + 1] = hi[l][m].im;
+        }
+}
+// bk: int64[PN][4][l][2048] -> spectral stream [pi][r][h][o][half][m][lane], scaled by 1/1024
+void emu_mk_transform_key_2k(const int64_t *bk, long PN, int l, double *spec) {
+    Wave2K w;
+    const int rows = 2 * l;
+    static cplx z[64][16], y0[64][8], y1[64][8];
+    cplx *out = reinterpret_cast<cplx *>(spec);
+    for (long pi = 0; pi < PN; pi++)
+        for (int r = 0; r < rows; r++)
+            for (int o = 0; o < 2; o++)
+                for (int h = 0; h < 4; h++) {
+                    const int j = r / l, lv = r % l;
+                    const int64_t *poly = bk + (((size_t)pi * 4 + mk_part_index(j, o)) * l + lv) * 2048;
+                    for (int ln = 0; ln < 64; ln++) key_limbs64_to_z16(ln, poly, h, z[ln]);
+                    w.fwd2k(z, y0, y1);
+                    cplx *dst = out + mk_chunk_index_2k(pi, r, h, o, rows) * 512;
+                    for (int ln = 0; ln < 64; ln++)
+                        for (int m = 0; m < 8; m++) {
+                            dst[m * 64 + ln] = cplx{y0[ln][m].re * (1.0 / 1024), y0[ln][m].im * (1.0 / 1024)};
+                            dst[512 + m * 64 + ln] = cplx{y1[ln][m].re * (1.0 / 1024), y1[ln][m].im * (1.0 / 1024)};
+                        }
+                }
+}
+// one CMux on acc int64[2][2048]; returns the worst distance of an inverse-transform output from an integer
+double emu_mk_mux_rotate_2k(const double *spec, int l, int Bgbit, long pi, int barai, int64_t *acc) {
+    Wave2K w;
+    const cplx *BK = reinterpret_cast<const cplx *>(spec);
+    const int rows = 2 * l, a2n = barai & 4095;
+    const uint64_t offset = decomp_offset64(l, Bgbit);
+    static cplx S0[2][4][64][8], S1[2][4][64][8], z[64][16], y0[64][8], y1[64][8], lo[64][8], hi[64][8];
+    static uint32_t t[64][32];
+    memset(S0, 0, sizeof(S0));
+    memset(S1, 0, sizeof(S1));
+    for (int r = 0; r < rows; r++) {
+        if (r % l == 0)
+            for (int ln = 0; ln < 64; ln++) load_rotated32_hi(ln, acc + (r / l) * 2048, a2n, offset, t[ln]);
+        for (int ln = 0; ln < 64; ln++) digits_to_z16(t[ln], (r % l) + 1, Bgbit, z[ln]);
+        w.fwd2k(z, y0, y1);
+        for (int o = 0; o < 2; o++)
+            for (int h = 0; h < 4; h++)
+                for (int ln = 0; ln < 64; ln++) {
+                    const cplx *B = BK + mk_chunk_index_2k(pi, r, h, o, rows) * 512;
+                    mac8(ln, S0[o][h][ln], y0[ln], B);
+                    mac8(ln, S1[o][h][ln], y1[ln], B + 512);
+                }
+    }
+    double worst = 0;
+    for (int o = 0; o < 2; o++)
+        for (int h = 0; h < 4; h++) {
+            w.inv2k(S0[o][h], S1[o][h], lo, hi);
+            for (int ln = 0; ln < 64; ln++)
+                for (int m = 0; m < 8; m++) {
+                    const int q = ln + 64 * m;
+                    const double v[4] = {lo[ln][m].re, hi[ln][m].re, lo[ln][m].im, hi[ln][m].im};
+                    const int idx[4] = {q, q + 512, q + 1024, q + 1536};
+                    for (int e = 0; e < 4; e++) {
+                        double d = __builtin_fabs(v[e] - __builtin_rint(v[e]));
+                        if (d > worst) worst = d;
+                        acc[o * 2048 + idx[e]] = (int64_t)((uint64_t)acc[o * 2048 + idx[e]] + ((uint64_t)round_i64(v[e]) << (16 * h)));
+                    }
+                }
+        }
+    return worst;
+}
+void emu_mk_extract_2k(const int64_t *acc, int32_t *out) {
+    for (int ln = 0; ln < 64; ln++) extract_64_n<2048>(ln, acc, acc + 2048, out);
+}
+}

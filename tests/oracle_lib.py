@@ -41,6 +41,7 @@ PARAM_SETS = {
     "MK2": dict(n=520, N=1024, k=1, l=2, Bgbit=7, ks_t=3, ks_basebit=3, torus_bits=64, parties=2),
     "MK3": dict(n=510, N=1024, k=1, l=2, Bgbit=7, ks_t=5, ks_basebit=2, torus_bits=64, parties=3),
     "MK4": dict(n=510, N=1024, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
+    "MK4-N2048": dict(n=510, N=2048, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
 }
 # noise standard deviations (torus units): J/api.jl:101-115 (SK-128: 2^-15 / 2^-25 per src/libthfhe.cpp:325-326),
 # J/mk_api.jl:32-38 (MK2), :84-90 (MK4)
@@ -51,6 +52,7 @@ SIGMAS = {
     "MK2": dict(lwe=2.0 ** -13.52, bk=2.0 ** -30.70, ks=2.0 ** -13.52),
     "MK3": dict(lwe=2.0 ** -13.26, bk=2.0 ** -30.70, ks=2.0 ** -13.26),
     "MK4": dict(lwe=2.0 ** -13.26, bk=2.0 ** -30.70, ks=2.0 ** -13.26),
+    "MK4-N2048": dict(lwe=2.0 ** -13.26, bk=2.0 ** -30.70, ks=2.0 ** -13.26),
 }
 
 

@@ -83,3 +83,42 @@ def test_mk4_bit_exact(O):
     assert np.array_equal(got, orc.gates(O.NAND, ca, cb))
     assert np.array_equal(K.decrypt_bits(got), ~(a.astype(bool) & b.astype(bool)))
     ck.close()
+
+
+def test_mk_n2048_reduced_n_all_gates_bit_exact(O):
+    # ring degree 2048 (BASELINE configs[4]): radix-2 split + two twisted 512-point transforms; l = 3 and l = 2 shapes
+    import thfhe
+    for name, over in (("MK4-N2048", dict(n=40, parties=2)), ("MK2", dict(n=33, N=2048))):
+        p = O.make_params(name, **over)
+        s = O.SIGMAS[name]
+        K = O.MKKeys(p, 11, s["bk"], s["ks"])
+        orc = O.MKOracle(p, K.bk, K.ksk)
+        ck = thfhe.MKCloudKey(thfhe.make_params(**p.as_dict()), K.bk, K.ksk, device=0)
+        a = np.array([0, 0, 1, 1, 1]); b = np.array([0, 1, 0, 1, 1]); c = np.array([1, 0, 1, 0, 0])
+        ca, cb, cc = (K.encrypt_bits(v, s["lwe"], 40 + q) for q, v in enumerate((a, b, c)))
+        for op, args in ((O.NAND, (ca, cb)), (O.XOR, (ca, cb)), (O.OR, (ca, cb)), (O.AND3, (ca, cb, cc)), (O.MUX, (ca, cb, cc))):
+            got = ck.gates(op, *args)
+            assert np.array_equal(got, orc.gates(op, *args)), (name, op)
+        assert np.array_equal(K.decrypt_bits(ck.gates(thfhe.NAND, ca, cb)), ~(a.astype(bool) & b.astype(bool)))
+        ref = np.stack([orc.keyswitch(orc.bootstrap_wo_keyswitch(r)) for r in ca[:2]])
+        assert np.array_equal(thfhe.mk_bootstrap_3gen(ck, thfhe.MU8_64, ca[:2]), ref)
+        ck.close()
+
+
+def test_mk4_n2048_full_size(O):
+    # BASELINE configs[4]: 4 parties, N = 2048, l = 3 at the reference's 4-party LWE dimension (n = 510)
+    import thfhe
+    p = O.make_params("MK4-N2048")
+    s = O.SIGMAS["MK4-N2048"]
+    K = O.MKKeys(p, 78, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    ck = thfhe.MKCloudKey(thfhe.make_params("MK4-N2048"), K.bk, K.ksk, device=0)
+    rng = np.random.default_rng(9)
+    B = 96
+    a, b = rng.integers(0, 2, B), rng.integers(0, 2, B)
+    ca, cb = K.encrypt_bits(a, s["lwe"], 1), K.encrypt_bits(b, s["lwe"], 2)
+    got = ck.gates(thfhe.NAND, ca, cb)
+    assert np.array_equal(got[:2], orc.gates(O.NAND, ca[:2], cb[:2]))
+    assert np.array_equal(K.decrypt_bits(got), ~(a.astype(bool) & b.astype(bool)))
+    assert np.array_equal(got, ck.gates(thfhe.NAND, ca, cb))   # deterministic
+    ck.close()

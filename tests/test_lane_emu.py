@@ -139,3 +139,53 @@ def test_cmux_l2_bgbit10(E, O):
     got = acc.copy()
     E.emu_mux_rotate(dptr(spec), p.l, p.Bgbit, 1, 777, O.p32(got))
     assert np.array_equal(ref, got)
+
+
+def test_2048_transform_matches_definition(E):
+    # P_k = sum_{j<1024} z_j zeta^(j(4k+1)), zeta = exp(i pi/2048); half = k & 1, k'' = k >> 1 in the 512-point register order
+    rng = np.random.default_rng(2)
+    z = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)
+    zin = np.ascontiguousarray(np.stack([z.real, z.imag], -1)).ravel()
+    out, back = np.zeros(2 * 64 * 8 * 2), np.zeros(2048)
+    E.emu_fwd_raw_2k(dptr(zin), dptr(out), dptr(back))
+    got = out.reshape(2, 64, 8, 2)
+    got = got[..., 0] + 1j * got[..., 1]
+    j = np.arange(1024)
+    k = np.arange(1024)
+    ang = (np.outer(4 * k + 1, j) % 4096) * (np.pi / 2048)
+    P = (np.exp(1j * ang) * z[None, :]).sum(axis=1)
+    exp = np.zeros((2, 64, 8), complex)
+    for half in range(2):
+        for k0 in range(8):
+            for k1 in range(8):
+                for k2 in range(8):
+                    exp[half, k1 + 8 * k0, k2] = P[2 * (k0 + 8 * k1 + 64 * k2) + half]
+    assert np.abs(got - exp).max() < 1e-9
+    zb = back.reshape(1024, 2)
+    assert np.abs((zb[:, 0] + 1j * zb[:, 1]) / 1024 - z).max() < 1e-13
+
+
+def test_mk_cmux_2048_bit_exact(E, O):
+    # BASELINE config 5 shape: 3-gen MK, N = 2048, l = 3, Bgbit = 6 -- lane code vs the oracle's schoolbook path
+    E.emu_mk_mux_rotate_2k.restype = C.c_double
+    p = O.make_params("MK4", n=2, parties=2, N=2048)
+    K = O.MKKeys(p, 3, 2.0**-30.70, 2.0**-13.52)
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    PN = p.parties * p.n
+    spec = np.zeros(PN * 2 * p.l * 8 * 1024 * 2, np.float64)
+    E.emu_mk_transform_key_2k(O.p64(K.bk), C.c_long(PN), p.l, dptr(spec))
+    acc = np.random.default_rng(6).integers(-2**63, 2**63, (2, 2048)).astype(np.int64)
+    for party, i, a in [(0, 0, 5), (1, 1, -2047), (0, 1, 2047), (1, 0, -2048), (1, 1, 1024)]:
+        ref = orc.mux_rotate(party, i, a, acc, schoolbook=True)
+        got = acc.copy()
+        margin = E.emu_mk_mux_rotate_2k(dptr(spec), p.l, p.Bgbit, C.c_long(party * p.n + i), a, O.p64(got))
+        assert np.array_equal(ref, got)
+        assert margin < 1e-3
+        acc = ref
+    out = np.zeros(2049, np.int32)
+    E.emu_mk_extract_2k(O.p64(acc), O.p32(out))
+    x = np.zeros(p.n * p.parties + 1, np.int32)      # all-zero mask words: bootstrap_wo_keyswitch only initialises + extracts
+    ref = orc.bootstrap_wo_keyswitch(x)
+    f = O.lib().oracle_t64tot32
+    exp = [f(int(acc[0, 0]))] + [f(int(((-int(acc[0, 2048 - q])) + 2**63) % 2**64 - 2**63)) for q in range(1, 2048)] + [f(int(acc[1, 0]))]
+    assert np.array_equal(out, np.array(exp, np.int32)) and ref.shape == (2049,)

@@ -1,0 +1,105 @@
+"""Party-sharded 3-gen MK bootstrap (thfhe.party_sharded).
+
+CPU: two gloo ranks rehearse the accumulator pipeline / broadcast / all-gather schedule with the CPU oracle playing each
+party's kernels; the result must equal the monolithic oracle bit for bit.
+GPU (-m gpu): two ranks share the one MI355X of the box, each with ONLY its party's keys in a parties=1 HIP context
+(gloo transport, staged through host memory); the result must equal the oracle and the replicated-key HIP path."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+RANK_SCRIPT = """
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, {tests!r}); sys.path.insert(0, {pkg!r})
+    import torch, torch.distributed as dist
+    import oracle_lib as O
+    import thfhe
+    from thfhe.party_sharded import PartyShardedEvaluator
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank = dist.get_rank()
+    mode = {mode!r}
+    p = O.make_params("MK2", **{over!r})
+    s = O.SIGMAS["MK2"]
+    K = O.MKKeys(p, 0x5EED0001, s["bk"], s["ks"])
+    tp = thfhe.make_params(**p.as_dict())
+    if mode == "oracle":
+        from party_oracle_backend import OraclePartyBackend
+        be = OraclePartyBackend(p, rank, K.bk[rank], K.ksk[rank])
+        dev = "cpu"
+    else:
+        from thfhe.party_sharded import HipPartyBackend
+        be = HipPartyBackend(tp, rank, K.bk[rank], K.ksk[rank], device=0)
+        dev = "cuda:0"
+    ev = PartyShardedEvaluator(tp, be, pipeline_chunks={chunks})
+    G = {gates}
+    rng = np.random.default_rng(3)
+    a, b, c = (rng.integers(0, 2, G) for _ in range(3))
+    xa, xb, xc = (K.encrypt_bits(v, s["lwe"], 900 + q) for q, v in enumerate((a, b, c)))
+    ta, tb, tc = (torch.from_numpy(v).to(dev) for v in (xa, xb, xc))
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    res = dict(rank=rank)
+    for name, op, args, targs in (("nand", O.NAND, (xa, xb), (ta, tb)), ("xor", O.XOR, (xa, xb), (ta, tb)),
+                                  ("and3", O.AND3, (xa, xb, xc), (ta, tb, tc)), ("mux", O.MUX, (xa, xb, xc), (ta, tb, tc)),
+                                  ("not", O.NOT, (xa,), (ta,))):
+        got = ev.gates(op, *targs).cpu().numpy()
+        res[name] = bool(np.array_equal(got, orc.gates(op, *args)))
+    got = ev.bootstrap(ta).cpu().numpy()
+    res["bootstrap"] = bool(np.array_equal(got, np.stack([orc.keyswitch(orc.bootstrap_wo_keyswitch(r)) for r in xa])))
+    res["decrypt"] = bool(np.array_equal(K.decrypt_bits(ev.gates(O.NAND, ta, tb).cpu().numpy()), ~(a.astype(bool) & b.astype(bool))))
+    if mode == "hip":   # the replicated-key kernel (all parties in one context) must agree too
+        ck = thfhe.MKCloudKey(tp, K.bk, K.ksk, device=0)
+        res["replica"] = bool(np.array_equal(ck.gates(O.NAND, xa, xb), ev.gates(O.NAND, ta, tb).cpu().numpy()))
+        ck.close()
+    dist.barrier()
+    print(json.dumps(res), flush=True)
+    dist.destroy_process_group()
+"""
+
+
+def run_two_ranks(tmp_path, mode, over, gates, chunks, timeout):
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent(RANK_SCRIPT.format(tests=os.path.join(ROOT, "tests"), pkg=os.path.join(ROOT, "torus-fhe_amd"),
+                                                         mode=mode, over=over, gates=gates, chunks=chunks)))
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for pr in procs:
+        so, se = pr.communicate(timeout=timeout)
+        assert pr.returncode == 0, se[-3000:]
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    return outs
+
+
+def test_party_pipeline_two_gloo_ranks_vs_oracle(tmp_path):
+    # reduced LWE dimension keeps the CPU oracle fast; ring degree, decomposition and key-switch shape are MK2's
+    outs = run_two_ranks(tmp_path, "oracle", dict(n=12), gates=5, chunks=2, timeout=600)
+    assert sorted(o["rank"] for o in outs) == [0, 1]
+    for o in outs:
+        assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt")), o
+
+
+@pytest.mark.gpu
+def test_party_sharded_two_ranks_one_gpu_bit_exact(tmp_path):
+    outs = run_two_ranks(tmp_path, "hip", dict(), gates=6, chunks=3, timeout=900)
+    for o in outs:
+        assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt", "replica")), o

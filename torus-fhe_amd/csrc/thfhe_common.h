@@ -83,6 +83,27 @@ __device__ __forceinline__ void wave_fft_inv_s(int lane, cplx (&z)[8], cplx *xb,
     wave_sync();
     invs_seg3(lane, z, xb, T1);
 }
+// N = 2048 halves: twisted 512-point transforms (thfhe_lane.h, "N = 2048" section); T1t = the table of twist T
+template <int T>
+__device__ __forceinline__ void wave_fft_fwd_t(int lane, cplx (&z)[8], cplx *xb, const cplx *T1t, const W64 &w) {
+    wave_sync();
+    fwdt_seg1<T>(lane, z, xb, T1t);
+    wave_sync();
+    fwds_seg2_ld(lane, z, xb);
+    fwds_seg2_st(lane, z, xb, w);
+    wave_sync();
+    fwds_seg3(lane, z, xb);
+}
+template <int T>
+__device__ __forceinline__ void wave_fft_inv_t(int lane, cplx (&z)[8], cplx *xb, const cplx *T1t, const W64 &w) {
+    wave_sync();
+    invs_seg1(lane, z, xb, w);
+    wave_sync();
+    invs_seg2_ld(lane, z, xb);
+    invs_seg2_st(lane, z, xb);
+    wave_sync();
+    invt_seg3<T>(lane, z, xb, T1t);
+}
 
 #endif
 

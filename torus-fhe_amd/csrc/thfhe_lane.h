@@ -467,6 +467,110 @@ THFHE_FN void extract16_64(int lane, const int64_t *acc_mask, const int64_t *acc
     if (lane == 0) out[1024] = t64tot32(acc_body[0]);
 }
 
+
+// ---- N = 2048 (BASELINE config 5): 1024 complex points = one radix-2 split + two twisted 512-point transforms -----------
+// z_j = p_j + i p_{j+1024}, P_k = sum_{j<1024} z_j zeta^(j(4k+1)), zeta = exp(i pi / 2048).  With j = j' + 512 s:
+//     zeta^(512 (4k+1)) = (-1)^k e^{i pi/4}, so
+//     P_{2k''}   = sum_{j'<512} (z_j' + e^{i pi/4} z_{j'+512}) zeta^(8 j' k'') zeta^(1 j')        ("twist" T = 1)
+//     P_{2k''+1} = sum_{j'<512} (z_j' - e^{i pi/4} z_{j'+512}) zeta^(8 j' k'') zeta^(5 j')        (T = 5)
+// Each half is the 512-point transform above with the twist zeta2^j' (= zeta^(2 j'), T = 2) replaced by zeta^(T j'): only
+// the pass-1 constants C_T[m] = zeta^(64 T m) = exp(i pi T m / 32) and the pass-1 table T1_T[k0][lane] = zeta^(lane (8 k0 + T))
+// change; passes 2 and 3 and the swizzled buffer maps are shared.  Spectrum register order: [half][slot m][lane].
+THFHE_FN cplx e32(int q) {  // exp(i pi q / 32)
+    constexpr double C[17] = {1.0, 0.995184726672196886231, 0.980785280403230449119, 0.956940335732208864931, 0.923879532511286756101,
+                              0.881921264348355029715, 0.831469612302545237081, 0.773010453362736960797, 0.707106781186547524382,
+                              0.634393284163645498203, 0.555570233019602224757, 0.471396736825997648545, 0.382683432365089771723,
+                              0.290284677254462367645, 0.195090322016128267857, 0.098017140329560601996, 0.0};
+    const int quad = (q >> 4) & 3, r = q & 15;
+    const double c = C[r], s = C[16 - r];
+    return quad == 0 ? cplx{c, s} : quad == 1 ? cplx{-s, c} : quad == 2 ? cplx{-c, -s} : cplx{s, -c};
+}
+template <int T>
+THFHE_FN void fwdt_seg1(int lane, cplx (&z)[8], cplx *xbuf, const cplx *T1t) {
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], e32(T * m));
+    dft8<+1>(z);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) xbuf[ys_a(k0, lane)] = cmul(z[k0], T1t[k0 * 64 + lane]);
+}
+template <int T>
+THFHE_FN void invt_seg3(int lane, cplx (&z)[8], const cplx *xbuf, const cplx *T1t) {
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) z[k0] = cmul_conj(xbuf[ys_a(k0, lane)], T1t[k0 * 64 + lane]);
+    dft8<-1>(z);
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], e32(T * m));
+}
+// radix-2 split of the 16 folded points a lane holds (z[m] <-> j = lane + 64 m) and its inverse (unnormalised: x2)
+THFHE_FN void split2048(const cplx (&z)[16], cplx (&y0)[8], cplx (&y1)[8]) {
+    constexpr double R = 0.70710678118654752440;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const cplx w{(z[m + 8].re - z[m + 8].im) * R, (z[m + 8].re + z[m + 8].im) * R};  // e^{i pi/4} z
+        y0[m] = cadd(z[m], w);
+        y1[m] = csub(z[m], w);
+    }
+}
+THFHE_FN void merge2048(const cplx (&a)[8], const cplx (&b)[8], cplx (&lo)[8], cplx (&hi)[8]) {
+    constexpr double R = 0.70710678118654752440;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const cplx d = csub(a[m], b[m]);
+        lo[m] = cadd(a[m], b[m]);
+        hi[m] = cplx{(d.re + d.im) * R, (d.im - d.re) * R};  // e^{-i pi/4} d
+    }
+}
+// generic-degree integer helpers (NN = ring degree, a power of two)
+template <int NN>
+THFHE_FN uint64_t rot_minus_self64_n(const int64_t *p, int q, int a2n) {
+    int e = (q - a2n) & (2 * NN - 1);
+    uint64_t r = (uint64_t)p[e & (NN - 1)];
+    if (e & NN) r = 0ull - r;
+    return r - (uint64_t)p[q];
+}
+// t[m] = top 32 bits of (X^a acc_j - acc_j)[lane + 64 m] + offset, m = 0..31   (N = 2048)
+THFHE_FN void load_rotated32_hi(int lane, const int64_t *acc_poly, int a2n, uint64_t offset, uint32_t (&t)[32]) {
+#pragma unroll
+    for (int m = 0; m < 32; m++) t[m] = (uint32_t)((rot_minus_self64_n<2048>(acc_poly, lane + 64 * m, a2n) + offset) >> 32);
+}
+THFHE_FN void digits_to_z16(const uint32_t (&t)[32], int p, int Bgbit, cplx (&z)[16]) {
+    const int shift = 32 - p * Bgbit;
+    const uint32_t mask = (1u << Bgbit) - 1u;
+    const int32_t half = 1 << (Bgbit - 1);
+#pragma unroll
+    for (int m = 0; m < 16; m++) z[m] = cplx{digit32(t[m], shift, mask, half), digit32(t[m + 16], shift, mask, half)};
+}
+THFHE_FN void key_limbs64_to_z16(int lane, const int64_t *poly, int h, cplx (&z)[16]) {  // limb h of a degree-2048 key polynomial
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        double a[4], b[4];
+        split_limbs64(poly[lane + 64 * m], a);
+        split_limbs64(poly[lane + 64 * m + 1024], b);
+        z[m] = cplx{a[h], b[h]};
+    }
+}
+template <int NN>
+THFHE_FN void acc_init_64_n(int lane, int64_t *acc_mask, int64_t *acc_body, int barb, int64_t mu) {
+#pragma unroll
+    for (int m = 0; m < NN / 64; m++) {
+        int q = lane + 64 * m;
+        int e = (q + barb) & (2 * NN - 1);
+        acc_mask[q] = 0;
+        acc_body[q] = (e & NN) ? (int64_t)(0ull - (uint64_t)mu) : mu;
+    }
+}
+template <int NN>
+THFHE_FN void extract_64_n(int lane, const int64_t *acc_mask, const int64_t *acc_body, int32_t *out) {
+#pragma unroll
+    for (int m = 0; m < NN / 64; m++) {
+        int q = lane + 64 * m;
+        out[q] = t64tot32(q == 0 ? acc_mask[0] : (int64_t)(0ull - (uint64_t)acc_mask[NN - q]));
+    }
+    if (lane == 0) out[NN] = t64tot32(acc_body[0]);
+}
+// spectral key stream for N = 2048: [party*n + i][row r][limb h][output o][half][slot m][lane], 16 KiB per (pi, r, h, o)
+THFHE_FN size_t mk_chunk_index_2k(long pi, int r, int h, int o, int rows) { return mk_chunk_index(pi, r, h, o, rows) * 2; }  // * 512 complex
+
 }  // namespace thfhe
 
 // ---- host-side twiddle table (double precision from long double; identical bytes on device) ---------
@@ -484,6 +588,16 @@ inline void make_twiddles_1024(cplx *T1 /*512*/, cplx *T2 /*64*/) {
         for (int j0 = 0; j0 < 8; j0++) {
             long double ang = 2.0L * PI * (long double)(j0 * k1) / 64.0L;
             T2[k1 * 8 + j0] = cplx{(double)cosl(ang), (double)sinl(ang)};
+        }
+}
+// N = 2048: T1_T[k0*64 + lane] = exp(i pi lane (8 k0 + T) / 2048) for the two twists T = 1 (even outputs) and T = 5 (odd outputs)
+inline void make_twiddles_2048(cplx *T1a /*512, T = 1*/, cplx *T1b /*512, T = 5*/) {
+    const long double PI = 3.14159265358979323846264338327950288L;
+    for (int k0 = 0; k0 < 8; k0++)
+        for (int lane = 0; lane < 64; lane++) {
+            long double a1 = PI * (long double)(lane * (8 * k0 + 1)) / 2048.0L, a5 = PI * (long double)(lane * (8 * k0 + 5)) / 2048.0L;
+            T1a[k0 * 64 + lane] = cplx{(double)cosl(a1), (double)sinl(a1)};
+            T1b[k0 * 64 + lane] = cplx{(double)cosl(a5), (double)sinl(a5)};
         }
 }
 }  // namespace thfhe

@@ -57,6 +57,36 @@ __global__ __launch_bounds__(256) void mk_key_transform_kernel(const int64_t *__
     }
 }
 
+// N = 2048: one wave per (pi, row, output, limb); two twisted 512-point spectra (even / odd outputs) per item, scaled by 1/1024
+__global__ __launch_bounds__(256) void mk_key_transform_2k_kernel(const int64_t *__restrict__ bk, long PN, int l,
+                                                                   const cplx *__restrict__ tw, cplx *__restrict__ spec) {
+    __shared__ cplx sT1[2][512];
+    __shared__ cplx sX[4][512];
+    for (int t = threadIdx.x; t < 1024; t += 256) (&sT1[0][0])[t] = tw[t];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const W64 w64{tw[1024 + 1 * 8 + (lane & 7)]};
+    const int rows = 2 * l;
+    const long item = (long)blockIdx.x * 4 + wave;  // (pi, r, o, h)
+    if (item >= PN * rows * 8) return;
+    const int h = (int)(item & 3), o = (int)((item >> 2) & 1);
+    const int r = (int)((item >> 3) % rows);
+    const long pi = (item >> 3) / rows;
+    const int j = r / l, lv = r % l;
+    const int64_t *poly = bk + (((size_t)pi * 4 + mk_part_index(j, o)) * l + lv) * 2048;
+    cplx z[16], y0[8], y1[8];
+    key_limbs64_to_z16(lane, poly, h, z);
+    split2048(z, y0, y1);
+    wave_fft_fwd_t<1>(lane, y0, sX[wave], sT1[0], w64);
+    wave_fft_fwd_t<5>(lane, y1, sX[wave], sT1[1], w64);
+    cplx *dst = spec + mk_chunk_index_2k(pi, r, h, o, rows) * 512;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        dst[m * 64 + lane] = cplx{y0[m].re * (1.0 / 1024), y0[m].im * (1.0 / 1024)};
+        dst[512 + m * 64 + lane] = cplx{y1[m].re * (1.0 / 1024), y1[m].im * (1.0 / 1024)};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // prologue: tmp = (0, cb) + cx x + cy y + cz z ; bara[job][P*n], barb[job]
 // ------------------------------------------------------------------------------------------------------
@@ -78,8 +108,8 @@ __host__ __device__ inline bool mk_gate_lin(int op, int which, MKLin &L) {
 }
 __global__ __launch_bounds__(256) void mk_prologue_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ in1,
                                                            const int32_t *__restrict__ in2, MKLin L0, MKLin L1, const int32_t *__restrict__ ops,
-                                                           int rot_per_gate, int words, int w_pad, long jobs, int32_t *__restrict__ bara,
-                                                           int32_t *__restrict__ barb) {
+                                                           int rot_per_gate, int words, int w_pad, int log2_2n, long jobs,
+                                                           int32_t *__restrict__ bara, int32_t *__restrict__ barb) {
     const long job = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (job >= jobs || i > words) return;
@@ -92,9 +122,9 @@ __global__ __launch_bounds__(256) void mk_prologue_kernel(const int32_t *__restr
     if (L.cz != 0) v += (uint32_t)L.cz * (uint32_t)in2[off];
     if (i == words) {
         v += (uint32_t)L.cb;
-        barb[job] = modswitch2n((int32_t)v, 11);
+        barb[job] = modswitch2n((int32_t)v, log2_2n);
     } else {
-        bara[job * w_pad + i] = modswitch2n((int32_t)v, 11);
+        bara[job * w_pad + i] = modswitch2n((int32_t)v, log2_2n);
     }
 }
 
@@ -111,6 +141,10 @@ struct MKBRArgs {
     int pn;               // parties * n : number of CMuxes
     int w_pad, Bgbit;
     int64_t mu;
+    // party-sharded mode (one rank per party): the accumulator enters from / leaves to global memory instead of being
+    // initialised / extracted here.  acc_in == nullptr: start from X^{-barb} * mu; acc_out == nullptr: extract into `out`.
+    const int64_t *acc_in = nullptr;
+    int64_t *acc_out = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -140,7 +174,11 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a
     const int32_t *bara = a.bara + job * a.w_pad;
     const int Bgbit = a.Bgbit;
     const uint64_t offset = decomp_offset64(L, Bgbit);
-    if (wave == 0) acc_init16_64(lane, sAcc, sAcc + 1024, a.barb[job], a.mu);
+    if (a.acc_in) {
+        for (int q = threadIdx.x; q < 2048; q += 512) sAcc[q] = a.acc_in[job * 2048 + q];
+    } else if (wave == 0) {
+        acc_init16_64(lane, sAcc, sAcc + 1024, a.barb[job], a.mu);
+    }
     __syncthreads();
     const int o = wave >> 2, h = wave & 3;
     unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc) + o * 1024;
@@ -181,7 +219,108 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a
         }
         __syncthreads();  // accumulator updated before anybody rotates it again
     }
-    if (wave == 0) extract16_64(lane, sAcc, sAcc + 1024, a.out + job * 1025);
+    if (a.acc_out) {
+        for (int q = threadIdx.x; q < 2048; q += 512) a.acc_out[job * 2048 + q] = sAcc[q];
+    } else if (wave == 0) {
+        extract16_64(lane, sAcc, sAcc + 1024, a.out + job * 1025);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// N = 2048 (BASELINE config 5).  Same wave roles as above; every 1024-point transform is a radix-2 split and two twisted
+// 512-point transforms (thfhe_lane.h), so a digit row publishes TWO half spectra (16 KiB) and a phase-2 wave keeps two
+// partial spectra S0 / S1.  LDS at l = 3: T1 tables 16 + accumulator 32 + spectra 96 = 144 KiB, so the transpose buffers
+// alias the spectrum area: in phase 1 wave r transposes inside its own (not yet published) spectrum slot, in phase 2 a third
+// barrier frees the whole area before the eight inverse transforms use 8 KiB of it each.
+// ------------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs a) {
+    constexpr int ROWS = 2 * L;
+    constexpr int SPEC_SLOTS = ROWS * 1024 > 8 * 512 ? ROWS * 1024 : 8 * 512;
+    __shared__ cplx sT1[2][512];
+    __shared__ int64_t sAcc[4096];
+    __shared__ cplx sSpec[SPEC_SLOTS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    for (int t = threadIdx.x; t < 1024; t += 512) (&sT1[0][0])[t] = a.tw[t];
+    const W64 w64{a.tw[1024 + 1 * 8 + (lane & 7)]};
+    const long job = blockIdx.x;
+    const int32_t *bara = a.bara + job * a.w_pad;
+    const int Bgbit = a.Bgbit;
+    const uint64_t offset = decomp_offset64(L, Bgbit);
+    if (a.acc_in) {
+        for (int q = threadIdx.x; q < 4096; q += 512) sAcc[q] = a.acc_in[job * 4096 + q];
+    } else if (wave == 0) {
+        acc_init_64_n<2048>(lane, sAcc, sAcc + 2048, a.barb[job], a.mu);
+    }
+    __syncthreads();
+    const int o = wave >> 2, h = wave & 3;
+    unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc) + o * 2048;
+
+    for (int i = 0; i < a.pn; i++) {
+        const int ai = bara[i];
+        if (ai == 0) continue;
+        const int a2n = ai & 4095;
+        if (wave < ROWS) {
+            cplx y0[8], y1[8];
+            {
+                uint32_t t[32];
+                cplx z[16];
+                load_rotated32_hi(lane, sAcc + (wave / L) * 2048, a2n, offset, t);
+                digits_to_z16(t, (wave % L) + 1, Bgbit, z);
+                split2048(z, y0, y1);
+            }
+            cplx *xb = sSpec + wave * 1024;
+            wave_fft_fwd_t<1>(lane, y0, xb, sT1[0], w64);
+            wave_fft_fwd_t<5>(lane, y1, xb, sT1[1], w64);
+            wave_sync();
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                xb[m * 64 + lane] = y0[m];
+                xb[512 + m * 64 + lane] = y1[m];
+            }
+        }
+        __syncthreads();  // spectra published; every rotated read of the accumulator is done
+        cplx S0[8], S1[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) S0[m] = S1[m] = cplx{0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const cplx *B = a.bk + mk_chunk_index_2k(i, r, h, o, ROWS) * 512;
+            cplx b0[8], b1[8], z0[8], z1[8];
+            load8(lane, b0, B);
+            load8(lane, b1, B + 512);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                z0[m] = sSpec[r * 1024 + m * 64 + lane];
+                z1[m] = sSpec[r * 1024 + 512 + m * 64 + lane];
+            }
+            mac8r(S0, z0, b0);
+            mac8r(S1, z1, b1);
+        }
+        __syncthreads();  // spectra consumed: the area is transpose scratch from here on
+        {
+            cplx *xb = sSpec + wave * 512;
+            wave_fft_inv_t<1>(lane, S0, xb, sT1[0], w64);
+            wave_fft_inv_t<5>(lane, S1, xb, sT1[1], w64);
+            cplx lo[8], hi[8];
+            merge2048(S0, S1, lo, hi);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int q = lane + 64 * m;
+                atomicAdd(accu + q, (unsigned long long)round_i64(lo[m].re) << (16 * h));
+                atomicAdd(accu + q + 512, (unsigned long long)round_i64(hi[m].re) << (16 * h));
+                atomicAdd(accu + q + 1024, (unsigned long long)round_i64(lo[m].im) << (16 * h));
+                atomicAdd(accu + q + 1536, (unsigned long long)round_i64(hi[m].im) << (16 * h));
+            }
+        }
+        __syncthreads();  // accumulator updated and scratch free before the next rotation
+    }
+    if (a.acc_out) {
+        for (int q = threadIdx.x; q < 4096; q += 512) a.acc_out[job * 4096 + q] = sAcc[q];
+    } else if (wave == 0) {
+        extract_64_n<2048>(lane, sAcc, sAcc + 2048, a.out + job * 2049);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -200,19 +339,20 @@ struct MKKSArgs {
     int32_t *out;        // [gates][P*n+1]
     long gates;
     int n, t, basebit, parties, row_words;
+    int N;  // ring degree = dimension of the extracted sample
 };
 
-// grid = (gates, parties, nsplit): block (g, p, s) key-switches coordinates [s*1024/nsplit, (s+1)*1024/nsplit) of gate g with
+// grid = (gates, parties, nsplit): block (g, p, s) key-switches coordinates [s*N/nsplit, (s+1)*N/nsplit) of gate g with
 // party p's key and adds its partial sum into the zero-initialised output with integer atomics (order-independent: bit-exact)
 __global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a, int nsplit) {
-    __shared__ uint32_t sA[1024];
+    __shared__ uint32_t sA[2048];
     __shared__ uint32_t sRed[4][768];
     const long g = blockIdx.x;
     const int p = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t prec_offset = 1u << (32 - (1 + a.basebit * a.t));
-    const int32_t *u = a.u + (size_t)g * 1025;
-    const int i_lo = (int)blockIdx.z * (1024 / nsplit), i_hi = i_lo + 1024 / nsplit;
+    const int32_t *u = a.u + (size_t)g * (a.N + 1);
+    const int i_lo = (int)blockIdx.z * (a.N / nsplit), i_hi = i_lo + a.N / nsplit;
     for (int q = i_lo + tid; q < i_hi; q += 256) sA[q] = (uint32_t)u[q] + prec_offset;
     __syncthreads();
     const int base1 = (1 << a.basebit) - 1;
@@ -222,7 +362,7 @@ __global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a, int nspli
     uint32_t r[12];
 #pragma unroll
     for (int q = 0; q < 12; q++) r[q] = 0;
-    const int32_t *kp = a.ksk + (size_t)p * 1024 * a.t * base1 * a.row_words;
+    const int32_t *kp = a.ksk + (size_t)p * a.N * a.t * base1 * a.row_words;
     for (int i = i_lo + wave; i < i_hi; i += 4) {
         const uint32_t ai = sA[i];
         for (int j = 0; j < a.t; j++) {
@@ -250,7 +390,7 @@ __global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a, int nspli
         if (q < a.n) {
             atomicAdd(out + (size_t)p * a.n + q, v);
         } else {
-            if (p == 0 && blockIdx.z == 0) v += (uint32_t)u[1024];  // b = b' + sum over parties of the parts' b
+            if (p == 0 && blockIdx.z == 0) v += (uint32_t)u[a.N];  // b = b' + sum over parties of the parts' b
             atomicAdd(out + (size_t)a.parties * a.n, v);
         }
     }
@@ -284,11 +424,12 @@ __global__ __launch_bounds__(256) void mk_mux_combine_kernel(const int32_t *__re
 struct thfhe_mk_ctx {
     thfhe_params p;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every call enqueues on
+    hipStream_t own_stream = nullptr;  // created with the context; `stream` differs only after thfhe_mk_set_stream
     cplx *d_bk = nullptr;
     int32_t *d_ksk = nullptr;
     cplx *d_tw = nullptr;
-    int row_words = 0, w_pad = 0, words = 0;
+    int row_words = 0, w_pad = 0, words = 0, log2_2n = 11;
     size_t cap_jobs = 0;
     int32_t *d_bara = nullptr, *d_barb = nullptr, *d_u = nullptr, *d_tmp = nullptr;
     size_t cap_stage = 0;
@@ -311,7 +452,7 @@ int mk_ensure_workspace(thfhe_mk_ctx *c, size_t jobs) {
     c->cap_jobs = 0;
     THFHE_HIP(hipMalloc(&c->d_bara, jobs * c->w_pad * sizeof(int32_t)));
     THFHE_HIP(hipMalloc(&c->d_barb, jobs * sizeof(int32_t)));
-    THFHE_HIP(hipMalloc(&c->d_u, jobs * 1025 * sizeof(int32_t)));
+    THFHE_HIP(hipMalloc(&c->d_u, jobs * ((size_t)c->p.N + 1) * sizeof(int32_t)));
     THFHE_HIP(hipMalloc(&c->d_tmp, jobs * (c->words + 1) * sizeof(int32_t)));
     c->cap_jobs = jobs;
     return THFHE_OK;
@@ -331,25 +472,23 @@ int mk_ensure_stage(thfhe_mk_ctx *c, size_t words) {
     return THFHE_OK;
 }
 
+int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a);
+
 // bootstrap (prologue + blind rotate + key switch) of `jobs` = gates * rot jobs; results to d_dst[jobs][P*n+1]
 int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1, const int32_t *d2, MKLin L0, MKLin L1, int rot,
                           size_t gates, int64_t mu, int32_t *d_dst, const int32_t *d_ops = nullptr) {
     const size_t jobs = gates * rot;
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[0], c->stream));
     dim3 pg((unsigned)((c->words + 1 + 255) / 256), (unsigned)jobs);
-    hipLaunchKernelGGL(mk_prologue_kernel, pg, dim3(256), 0, c->stream, d0, d1, d2, L0, L1, d_ops, rot, c->words, c->w_pad, (long)jobs, c->d_bara, c->d_barb);
+    hipLaunchKernelGGL(mk_prologue_kernel, pg, dim3(256), 0, c->stream, d0, d1, d2, L0, L1, d_ops, rot, c->words, c->w_pad, c->log2_2n, (long)jobs, c->d_bara, c->d_barb);
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[1], c->stream));
     MKBRArgs a{c->d_bk, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)jobs, c->p.parties * c->p.n, c->w_pad, c->p.Bgbit, mu};
-    const dim3 grid((unsigned)jobs), block(512);
-    switch (c->p.l) {
-    case 1: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<1>, grid, block, 0, c->stream, a); break;
-    case 2: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<2>, grid, block, 0, c->stream, a); break;
-    case 3: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<3>, grid, block, 0, c->stream, a); break;
-    case 4: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<4>, grid, block, 0, c->stream, a); break;
-    default: return thfhe_fail(THFHE_E_UNSUPPORTED, "decomposition length l must be 1..4");
+    {
+        int rc = mk_launch_rotation(c, a);
+        if (rc) return rc;
     }
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[2], c->stream));
-    MKKSArgs k{c->d_ksk, c->d_u, d_dst, (long)jobs, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words};
+    MKKSArgs k{c->d_ksk, c->d_u, d_dst, (long)jobs, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words, c->p.N};
     const int nsplit = jobs * c->p.parties <= 64 ? 16 : (jobs * c->p.parties <= 256 ? 4 : 1);  // fill the chip at small batch sizes
     THFHE_HIP(hipMemsetAsync(d_dst, 0, jobs * ((size_t)c->words + 1) * sizeof(int32_t), c->stream));
     hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)jobs, (unsigned)c->p.parties, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
@@ -359,6 +498,59 @@ int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1,
     }
     THFHE_HIP(hipGetLastError());
     return THFHE_OK;
+}
+
+int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a) {
+    const dim3 grid((unsigned)a.jobs), block(512);
+    if (c->p.N == 2048) {
+        switch (c->p.l) {
+        case 1: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<1>, grid, block, 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<2>, grid, block, 0, c->stream, a); break;
+        case 3: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<3>, grid, block, 0, c->stream, a); break;
+        default: return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 2048 needs decomposition length l <= 3");
+        }
+        THFHE_HIP(hipGetLastError());
+        return THFHE_OK;
+    }
+    switch (c->p.l) {
+    case 1: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<1>, grid, block, 0, c->stream, a); break;
+    case 2: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<2>, grid, block, 0, c->stream, a); break;
+    case 3: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<3>, grid, block, 0, c->stream, a); break;
+    case 4: hipLaunchKernelGGL(mk_blind_rotate_coop_kernel<4>, grid, block, 0, c->stream, a); break;
+    default: return thfhe_fail(THFHE_E_UNSUPPORTED, "decomposition length l must be 1..4");
+    }
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+
+__global__ __launch_bounds__(256) void mk_extract_kernel(const int64_t *__restrict__ acc, int32_t *__restrict__ out, long jobs, int N) {
+    const long job = blockIdx.x;
+    if (job >= jobs) return;
+    const int64_t *ap = acc + job * 2 * N;
+    for (int q = threadIdx.x; q <= N; q += 256) {
+        int64_t v = q == N ? ap[N] : (q == 0 ? ap[0] : (int64_t)(0ull - (uint64_t)ap[N - q]));
+        out[job * (N + 1) + q] = t64tot32(v);
+    }
+}
+
+// party-sharded prologue: the gate's linear part + mod-switch for ONE party's n mask words (record words
+// [first_word, first_word + n)) and for b.  Records have rec_words = P_total * n + 1 words.
+__global__ __launch_bounds__(256) void mk_prologue_slice_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ in1,
+                                                                 const int32_t *__restrict__ in2, MKLin L, int rec_words, int first_word, int n,
+                                                                 int log2_2n, long jobs, int32_t *__restrict__ bara, int32_t *__restrict__ barb) {
+    const long job = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (job >= jobs || i > n) return;
+    const size_t off = (size_t)job * rec_words + (i == n ? rec_words - 1 : first_word + i);
+    uint32_t v = (uint32_t)L.cx * (uint32_t)in0[off];
+    if (L.cy != 0) v += (uint32_t)L.cy * (uint32_t)in1[off];
+    if (L.cz != 0) v += (uint32_t)L.cz * (uint32_t)in2[off];
+    if (i == n) {
+        v += (uint32_t)L.cb;
+        barb[job] = modswitch2n((int32_t)v, log2_2n);
+    } else {
+        bara[job * n + i] = modswitch2n((int32_t)v, log2_2n);
+    }
 }
 
 int mk_gates_dev_locked(thfhe_mk_ctx *c, int op, const int32_t *d0, const int32_t *d1, const int32_t *d2, int32_t *dout, size_t count) {
@@ -401,7 +593,8 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     if (!p || !bk_coeff || !ksk || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
     *out = nullptr;
     if (p->torus_bits != 64) return thfhe_fail(THFHE_E_UNSUPPORTED, "thfhe_mk_ctx_create is the Torus64 3-gen multi-key path");
-    if (p->N != 1024 || p->k != 1) return thfhe_fail(THFHE_E_UNSUPPORTED, "only N = 1024, k = 1 is implemented");
+    if ((p->N != 1024 && p->N != 2048) || p->k != 1) return thfhe_fail(THFHE_E_UNSUPPORTED, "only N = 1024 / 2048, k = 1 is implemented");
+    if (p->N == 2048 && p->l > 3) return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 2048 needs decomposition length l <= 3");
     if (p->parties < 1 || p->parties > 16) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= parties <= 16");
     if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || p->Bgbit > 10 || p->l * p->Bgbit > 32)
         return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 4, Bgbit <= 10 (FP64 exactness bound), l*Bgbit <= 32");
@@ -418,6 +611,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     c->words = p->parties * p->n;
     c->w_pad = (c->words + 3) & ~3;
     c->row_words = 128 * ((p->n + 1 + 127) / 128);
+    c->log2_2n = ilog2(2 * p->N);
     auto fail = [&](int code) {
         thfhe_mk_ctx_destroy(c);
         return code;
@@ -427,23 +621,35 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
         hipError_t e_ = (expr);                                       \
         if (e_ != hipSuccess) return fail(thfhe_fail_hip(e_, #expr)); \
     } while (0)
-    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
     for (auto &e : c->ev) CK(hipEventCreate(&e));
-    std::vector<cplx> tw(576);
-    make_twiddles_1024(tw.data(), tw.data() + 512);
+    std::vector<cplx> tw(1088);  // N = 1024: T1[512] T2[64]; N = 2048: T1(twist 1)[512] T1(twist 5)[512] T2[64]
+    if (p->N == 2048) {
+        std::vector<cplx> unused(512);
+        make_twiddles_2048(tw.data(), tw.data() + 512);
+        make_twiddles_1024(unused.data(), tw.data() + 1024);
+    } else {
+        make_twiddles_1024(tw.data(), tw.data() + 512);
+    }
     CK(hipMalloc(&c->d_tw, tw.size() * sizeof(cplx)));
     CK(hipMemcpyAsync(c->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
     const long PN = (long)p->parties * p->n;
-    const size_t coeff_words = (size_t)PN * 4 * p->l * 1024;
+    const size_t coeff_words = (size_t)PN * 4 * p->l * p->N;
     int64_t *d_coeff = nullptr;
     CK(hipMalloc(&d_coeff, coeff_words * sizeof(int64_t)));
     CK(hipMemcpyAsync(d_coeff, bk_coeff, coeff_words * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     const size_t chunks = (size_t)PN * 2 * p->l * 8;
-    CK(hipMalloc(&c->d_bk, chunks * 512 * sizeof(cplx)));
-    const long items = PN * 2 * p->l * 2;
-    hipLaunchKernelGGL(mk_key_transform_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, c->stream, d_coeff, PN, p->l, c->d_tw, c->d_bk);
+    CK(hipMalloc(&c->d_bk, chunks * (p->N / 2) * sizeof(cplx)));
+    if (p->N == 2048) {
+        const long items = PN * 2 * p->l * 8;
+        hipLaunchKernelGGL(mk_key_transform_2k_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, c->stream, d_coeff, PN, p->l, c->d_tw, c->d_bk);
+    } else {
+        const long items = PN * 2 * p->l * 2;
+        hipLaunchKernelGGL(mk_key_transform_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, c->stream, d_coeff, PN, p->l, c->d_tw, c->d_bk);
+    }
     CK(hipGetLastError());
-    const long rows = (long)p->parties * 1024 * p->ks_t * ((1 << p->ks_basebit) - 1);
+    const long rows = (long)p->parties * p->N * p->ks_t * ((1 << p->ks_basebit) - 1);
     int32_t *d_raw = nullptr;
     CK(hipMalloc(&d_raw, (size_t)rows * (p->n + 1) * sizeof(int32_t)));
     CK(hipMemcpyAsync(d_raw, ksk, (size_t)rows * (p->n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -461,7 +667,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
 void thfhe_mk_ctx_destroy(thfhe_mk_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     (void)hipFree(c->d_bk);
     (void)hipFree(c->d_ksk);
     (void)hipFree(c->d_tw);
@@ -473,7 +679,7 @@ void thfhe_mk_ctx_destroy(thfhe_mk_ctx *c) {
     (void)hipFree(c->d_out);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -575,6 +781,61 @@ int thfhe_mk_gates_mixed(thfhe_mk_ctx *c, const int32_t *ops, const int32_t *in0
     if (rc) return rc;
     THFHE_HIP(hipMemcpyAsync(out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+// ---- party-sharded building blocks (device pointers; see include/thfhe_hip.h and thfhe/party_sharded.py) -------------------
+int thfhe_mk_rotate_partial_dev(thfhe_mk_ctx *c, const int32_t *d_bara, const int32_t *d_barb, int64_t mu, const int64_t *d_acc_in,
+                                int64_t *d_acc_out, size_t count) {
+    if (!c || !d_bara || !d_acc_out || (!d_acc_in && !d_barb)) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    MKBRArgs a{c->d_bk, c->d_tw, d_bara, d_barb, nullptr, (long)count, c->p.parties * c->p.n, c->words, c->p.Bgbit, mu, d_acc_in, d_acc_out};
+    return mk_launch_rotation(c, a);
+}
+int thfhe_mk_prologue_dev(thfhe_mk_ctx *c, int op, int which, const int32_t *d0, const int32_t *d1, const int32_t *d2, int rec_words,
+                          int first_word, int32_t *d_bara, int32_t *d_barb, size_t count) {
+    if (!c || !d0 || !d_bara || !d_barb) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    MKLin L;
+    if (op == -1) op = kOpIdentity;  // plain bootstrap of in0
+    if (!mk_gate_lin(op, which, L)) return thfhe_fail(THFHE_E_INVALID, "gate not defined for the 3-gen multi-key scheme");
+    if ((L.cy != 0 && !d1) || (L.cz != 0 && !d2)) return thfhe_fail(THFHE_E_INVALID, "null operand");
+    if (first_word < 0 || first_word + c->p.n > rec_words - 1) return thfhe_fail(THFHE_E_INVALID, "party slice outside the record");
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const dim3 grid((unsigned)((c->p.n + 1 + 255) / 256), (unsigned)count);
+    hipLaunchKernelGGL(mk_prologue_slice_kernel, grid, dim3(256), 0, c->stream, d0, d1, d2, L, rec_words, first_word, c->p.n, c->log2_2n, (long)count, d_bara, d_barb);
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+int thfhe_mk_set_stream(thfhe_mk_ctx *c, void *hip_stream) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return THFHE_OK;
+}
+int thfhe_mk_extract_dev(thfhe_mk_ctx *c, const int64_t *d_acc, int32_t *d_u, size_t count) {
+    if (!c || !d_acc || !d_u) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    hipLaunchKernelGGL(mk_extract_kernel, dim3((unsigned)count), dim3(256), 0, c->stream, d_acc, d_u, (long)count, c->p.N);
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+int thfhe_mk_keyswitch_dev(thfhe_mk_ctx *c, const int32_t *d_u, int32_t *d_out, size_t count) {
+    if (!c || !d_u || !d_out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    MKKSArgs k{c->d_ksk, d_u, d_out, (long)count, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words, c->p.N};
+    const int nsplit = count * c->p.parties <= 64 ? 16 : (count * c->p.parties <= 256 ? 4 : 1);
+    THFHE_HIP(hipMemsetAsync(d_out, 0, count * ((size_t)c->words + 1) * sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)count, (unsigned)c->p.parties, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
+    THFHE_HIP(hipGetLastError());
     return THFHE_OK;
 }
 

@@ -42,6 +42,8 @@ PARAM_SETS = {
     "MK2": dict(n=520, N=1024, k=1, l=2, Bgbit=7, ks_t=3, ks_basebit=3, torus_bits=64, parties=2),
     "MK3": dict(n=510, N=1024, k=1, l=2, Bgbit=7, ks_t=5, ks_basebit=2, torus_bits=64, parties=3),
     "MK4": dict(n=510, N=1024, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
+    # BASELINE.json configs[4] wording ("4-party 3-gen MK-TFHE, N=2048 l=3"): the reference's 4-party set on the larger ring
+    "MK4-N2048": dict(n=510, N=2048, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
 }
 
 
@@ -84,6 +86,11 @@ SIGNATURES = {
     "thfhe_mk_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_gates_mixed": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_bootstrap": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, C.c_size_t]),
+    "thfhe_mk_prologue_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_size_t]),
+    "thfhe_mk_set_stream": (C.c_int, [_vp, _vp]),
+    "thfhe_mk_rotate_partial_dev": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_size_t]),
+    "thfhe_mk_extract_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "thfhe_mk_keyswitch_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "thfhe_mk_dev_alloc": (_vp, [_vp, C.c_size_t]),
     "thfhe_mk_dev_free": (None, [_vp, _vp]),
     "thfhe_mk_copy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
