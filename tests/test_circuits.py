@@ -130,3 +130,78 @@ def test_mk_adder_demo_on_gpu(O):
         out = K.decrypt_bits(vals[s])
         assert sum(int(x) << i for i, x in enumerate(out)) == m1 + m2
     ck.close()
+
+
+def build_knn(nb, ncol, ntrain):
+    from thfhe import circuits as Cc
+    cir = Cc.Circuit()
+    test_row = [cir.inputs(nb) for _ in range(ncol)]
+    train = [[cir.inputs(nb) for _ in range(ncol)] for _ in range(ntrain)]
+    threshold, all_zero, all_one, lsb_one = (cir.inputs(nb) for _ in range(4))
+    zero = cir.inputs(1)[0]
+    decision, count, sdists = Cc.knn_classify(cir, test_row, train, threshold, all_zero, all_one, lsb_one, zero, zero)
+    return cir, decision, count, sdists
+
+
+def knn_plain_inputs(nb, test_row, train, threshold):
+    bits = []
+    for w in test_row:
+        bits += bits_msb(w, nb)
+    for r in train:
+        for w in r:
+            bits += bits_msb(w, nb)
+    return bits + bits_msb(threshold, nb) + [0] * nb + [1] * nb + bits_msb(1, nb) + [0]
+
+
+def test_full_knn_circuit_plaintext_and_census():
+    # src/KNN_medical_data.cpp:676-732 on a reduced shape: distances over columns 1..ncol-2, MUX copy, bubble sort with
+    # the records as payload, vote over the label column, decision = sign(threshold - count)
+    from thfhe import circuits as Cc
+    import thfhe
+    nb, ncol, ntrain = 8, 4, 3
+    cir, decision, count, sdists = build_knn(nb, ncol, ntrain)
+    rng = np.random.default_rng(1)
+    for trial in range(6):
+        test_row = [0] + [int(v) for v in rng.integers(0, 50, ncol - 2)] + [int(rng.integers(0, 2))]
+        train = [[i] + [int(v) for v in rng.integers(0, 50, ncol - 2)] + [int(rng.integers(0, 2))] for i in range(ntrain)]
+        threshold = ntrain // 2
+        v = Cc.simulate(cir, knn_plain_inputs(nb, test_row, train, threshold))
+        d = [sum(abs(test_row[c] - r[c]) for c in range(1, ncol - 1)) for r in train]
+        assert [from_bits(v[w]) for w in sdists] == sorted(d)
+        votes = sum(r[ncol - 1] for r in train)          # K = all train rows, as in the reference (K = train_row_size = 5)
+        assert from_bits(v[count]) == votes
+        assert bool(v[decision]) == (votes > threshold)
+    # census of the reference-sized circuit: 5 train rows, 14 columns, 32 bit
+    cir, *_ = build_knn(32, 14, 5)
+    cs = cir.census()
+    fa, dif = 159, 32 + 2 * 159
+    dist_bw = 12 * (2 * dif + 32 + fa)                   # two-input gates + 32 MUX per column
+    exp_two = 5 * (dist_bw - 12 * 32) + 20 * (dif + 2 * 15 * 32) + 5 * fa + dif + 1
+    exp_mux = 5 * 12 * 32 + 5 * 14 * 32 + 20 * 2 * 15 * 32
+    assert cs["mux"] == exp_mux and cs["gates"] == exp_two + exp_mux
+    assert cs["rotations"] == exp_two + 2 * exp_mux      # ~1.26e5 blind rotations
+    assert 1.2e5 < cs["rotations"] < 1.3e5
+
+
+@pytest.mark.gpu
+def test_reduced_knn_decision_on_gpu():
+    # the whole KNN decision DAG (distances, copy, sort with payload, vote, decision) at 8 bit x 4 columns x 3 train rows
+    import thfhe
+    from thfhe import keygen, circuits as Cc
+    nb, ncol, ntrain = 8, 4, 3
+    cir, decision, count, sdists = build_knn(nb, ncol, ntrain)
+    test_row = [0, 17, 40, 1]
+    train = [[1, 20, 35, 1], [2, 3, 44, 0], [3, 16, 41, 1]]
+    p = thfhe.make_params("SK-128")
+    K = keygen.SecretKeySet(p, seed=0x5EED0001)
+    ck = thfhe.CloudKey(p, K.bk, K.ksk, device=0)
+    plain = knn_plain_inputs(nb, test_row, train, ntrain // 2)
+    stats = {}
+    vals = Cc.evaluate(ck, cir, K.encrypt(np.array(plain), seed=5), stats)
+    sim = Cc.simulate(cir, plain)
+    assert np.array_equal(K.decrypt(vals), sim)                       # every wire of the DAG decrypts to the plaintext simulation
+    d = sorted(sum(abs(test_row[c] - r[c]) for c in range(1, ncol - 1)) for r in train)
+    assert [from_bits(K.decrypt(vals[w])) for w in sdists] == d
+    assert from_bits(K.decrypt(vals[count])) == 2 and bool(K.decrypt(vals[[decision]])[0])
+    assert stats["launches"] < stats["gates"] / 4                      # levelised: far fewer launches than gates
+    ck.close()

@@ -101,6 +101,55 @@ def distance_bw_data(cir, row_a, row_b, all_zero, all_one, lsb_one, zero):
     return result
 
 
+def copy_through_mux(cir, all_one, x):
+    """The reference copies a word with bootsMUX(allOne[l], x[l], x[l]), :685-689 (a bootstrapped refresh)."""
+    return [cir.gate(MUX, all_one[i], x[i], x[i]) for i in range(len(x))]
+
+
+def compare_swap(cir, key_a, key_b, payload_a, payload_b, all_zero, all_one, lsb_one, zero):
+    """One step of sort_with_distance, :443-481: diff = key_a - key_b; its sign bit routes the smaller key (and its
+    payload words) to position a and the bigger to position b through MUXes; every routed bit is then refreshed with
+    XOR(., allZero).  Returns (key_a', key_b', payload_a', payload_b')."""
+    diff = difference(cir, key_a, key_b, all_one, lsb_one, zero)
+    s = diff[0]
+    nb = len(key_a)
+    big = [cir.gate(MUX, s, key_b[j], key_a[j]) for j in range(nb)]
+    small = [cir.gate(MUX, s, key_a[j], key_b[j]) for j in range(nb)]
+    pay_big = [[cir.gate(MUX, s, wb[j], wa[j]) for j in range(nb)] for wa, wb in zip(payload_a, payload_b)]
+    pay_small = [[cir.gate(MUX, s, wa[j], wb[j]) for j in range(nb)] for wa, wb in zip(payload_a, payload_b)]
+    refresh = lambda w: [cir.gate(XOR, w[j], all_zero[j]) for j in range(nb)]
+    return refresh(small), refresh(big), [refresh(w) for w in pay_small], [refresh(w) for w in pay_big]
+
+
+def sort_with_distance(cir, rows, dists, all_zero, all_one, lsb_one, zero):
+    """sort_with_distance, :410-489: n passes of adjacent compare-swaps (bubble sort) on the distances, the train records
+    moving with them.  rows[i] = list of words, dists[i] = word.  Returns (rows, dists) sorted by ascending distance."""
+    rows, dists = [list(r) for r in rows], list(dists)
+    n = len(dists)
+    for _ in range(n):
+        for i in range(1, n):
+            dists[i - 1], dists[i], rows[i - 1], rows[i] = compare_swap(cir, dists[i - 1], dists[i], rows[i - 1], rows[i],
+                                                                        all_zero, all_one, lsb_one, zero)
+    return rows, dists
+
+
+def knn_classify(cir, test_row, train_rows, threshold, all_zero, all_one, lsb_one, lsb_zero_carry, zero, K=None):
+    """The reference's KNN decision for one test record, :676-732: Manhattan distances to every train row (columns
+    1..col_size-2), a MUX copy of the train rows, sort by distance, count = sum of the label column of the K nearest,
+    decision = XOR(sign(threshold - count), 0).  Returns (decision_wire, count_word, sorted_dists)."""
+    ncol = len(test_row)
+    n = len(train_rows)
+    K = n if K is None else K
+    dists = [distance_bw_data(cir, test_row[:ncol - 1], tr[:ncol - 1], all_zero, all_one, lsb_one, zero) for tr in train_rows]
+    copies = [[copy_through_mux(cir, all_one, w) for w in tr] for tr in train_rows]
+    srows, sdists = sort_with_distance(cir, copies, dists, all_zero, all_one, lsb_one, zero)
+    count = list(all_zero)
+    for j in range(K):
+        count, _ = full_adder(cir, count, srows[j][ncol - 1], lsb_zero_carry)
+    diff = difference(cir, threshold, count, all_one, lsb_one, zero)
+    return cir.gate(XOR, diff[0], all_zero[0]), count, sdists
+
+
 # ---- the reference's multi-key integer circuits (3gen_mk_gates.jl; bit vectors LSB-first, mk_api.jl:563-576) ----------
 def mk_add_3gen(cir, a, b, cin):
     """mk_add_3gen / mk_add_3gen_v2, 3gen_mk_gates.jl:183-220."""
