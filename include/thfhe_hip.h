@@ -118,6 +118,9 @@ int thfhe_mk_gates(thfhe_mk_ctx *ctx, int op, const int32_t *in0, const int32_t 
                    int32_t *out, size_t count);
 /* one launch for a DAG level of two-input 3-gen gates (NAND / OR / AND / XOR), per-gate opcodes in the HOST array ops */
 int thfhe_mk_gates_mixed(thfhe_mk_ctx *ctx, const int32_t *ops, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count);
+/* Batches of at most `max_single_jobs` rotations run one gate per workgroup (latency), larger ones two gates per workgroup sharing
+ * every key chunk (throughput; N = 1024, l <= 3).  Default 256 = one workgroup per CU of an MI355X. */
+int thfhe_mk_set_pair_threshold(thfhe_mk_ctx *ctx, long max_single_jobs);
 int thfhe_mk_bootstrap(thfhe_mk_ctx *ctx, int64_t mu, const int32_t *x, int32_t *out, size_t count);
 /* Party-sharded building blocks (optional mode: one rank per party holds only that party's keys, i.e. a
  * context created with parties = 1 from party p's key part).  All pointers are DEVICE pointers; calls enqueue on the context's

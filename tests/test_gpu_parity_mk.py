@@ -122,3 +122,42 @@ def test_mk4_n2048_full_size(O):
     assert np.array_equal(K.decrypt_bits(got), ~(a.astype(bool) & b.astype(bool)))
     assert np.array_equal(got, ck.gates(thfhe.NAND, ca, cb))   # deterministic
     ck.close()
+
+
+def test_mk_pair_kernel_bit_exact(O, mk2gpu):
+    # throughput kernel (two gates per workgroup share every key chunk): forced for small odd batches, incl. a zero mod-switched
+    # mask word in one gate of a pair (that gate skips the CMux, its partner does not) and a lone last gate
+    import thfhe
+    p, K, orc, ck = mk2gpu
+    s = O.SIGMAS["MK2"]
+    rng = np.random.default_rng(12)
+    a, b, c = (rng.integers(0, 2, 7) for _ in range(3))
+    ca, cb, cc = (K.encrypt_bits(v, s["lwe"], 700 + q) for q, v in enumerate((a, b, c)))
+    ca[0, 3] = cb[0, 3] = 0           # bara = 0 for gate 0 at i = 3, not for gate 1
+    ca[2, 600] = cb[2, 600] = 0       # second party's range
+    ca[6, 0] = cb[6, 0] = 0           # the lone gate of the last workgroup
+    ck.set_pair_threshold(0)
+    try:
+        for op, args in ((O.NAND, (ca, cb)), (O.XOR, (ca, cb)), (O.AND3, (ca, cb, cc)), (O.MUX, (ca, cb, cc))):
+            assert np.array_equal(ck.gates(op, *args), orc.gates(op, *args)), op
+        ops = np.array([O.NAND, O.OR, O.AND, O.XOR, O.NAND, O.XOR, O.OR], np.int32)
+        ref = np.stack([orc.gates(int(o), ca[i:i + 1], cb[i:i + 1])[0] for i, o in enumerate(ops)])
+        assert np.array_equal(ck.gates_mixed(ops, ca, cb), ref)
+    finally:
+        ck.set_pair_threshold(256)
+
+
+def test_mk4_pair_kernel_bit_exact(O):
+    import thfhe
+    p = O.make_params("MK4", n=48)     # l = 3: twelve forward transforms per step on eight waves
+    s = O.SIGMAS["MK4"]
+    K = O.MKKeys(p, 79, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    ck = thfhe.MKCloudKey(thfhe.make_params(**p.as_dict()), K.bk, K.ksk, device=0)
+    ck.set_pair_threshold(0)
+    a = np.array([0, 1, 1, 0, 1]); b = np.array([1, 1, 0, 0, 1])
+    ca, cb = K.encrypt_bits(a, s["lwe"], 1), K.encrypt_bits(b, s["lwe"], 2)
+    got = ck.gates(thfhe.NAND, ca, cb)
+    assert np.array_equal(got, orc.gates(O.NAND, ca, cb))
+    assert np.array_equal(K.decrypt_bits(got), ~(a.astype(bool) & b.astype(bool)))
+    ck.close()

@@ -227,6 +227,108 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Throughput kernel: one 512-thread workgroup = TWO gates.  The cooperative kernel above is bound by the key bytes a CU
+// has to pull through its vector-memory path (2l x 4 limbs x 2 outputs x 8 KiB = 256 KiB per CMux at l = 2, ~13 k cycles at the
+// measured ~20 B/clk/CU, against ~5 k cycles of FP64 work).  Here every (output, limb) wave multiplies its key chunks into the
+// spectra of two gates, so each key byte serves two CMuxes; the 2 x 2l forward transforms of a step keep all eight waves busy in
+// phase 1 (l = 2: one each), and the transpose scratch aliases the spectrum area (a third barrier frees it for the inverses), which is
+// what lets two accumulators and two sets of spectra fit: T1 8 + acc 32 + spectra 2 x 2l x 8 KiB (l = 3: 136 KiB).
+// ------------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a) {
+    constexpr int ROWS = 2 * L;
+    constexpr int FFTS = 2 * ROWS;
+    constexpr int SPEC_SLOTS = (FFTS > 8 ? FFTS : 8) * 512;
+    constexpr int PRE = ROWS <= 4 ? ROWS : 2;  // key rows in flight (32 VGPRs each)
+    __shared__ cplx sT1[512];
+    __shared__ int64_t sAcc[2][2048];
+    __shared__ cplx sSpec[SPEC_SLOTS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    sT1[threadIdx.x] = a.tw[threadIdx.x];
+    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
+    const long job0 = 2 * (long)blockIdx.x;
+    const bool has1 = job0 + 1 < a.jobs;
+    const int32_t *bara0 = a.bara + job0 * a.w_pad;
+    const int32_t *bara1 = bara0 + (has1 ? a.w_pad : 0);
+    const int Bgbit = a.Bgbit;
+    const uint64_t offset = decomp_offset64(L, Bgbit);
+    if (wave < 2 && (wave == 0 || has1)) acc_init16_64(lane, sAcc[wave], sAcc[wave] + 1024, a.barb[job0 + wave], a.mu);
+    __syncthreads();
+    const int o = wave >> 2, h = wave & 3;
+
+    for (int i = 0; i < a.pn; i++) {
+        const int ai0 = bara0[i], ai1 = has1 ? bara1[i] : 0;  // uniform over the workgroup
+        if (ai0 == 0 && ai1 == 0) continue;
+#pragma unroll
+        for (int f0 = 0; f0 < FFTS; f0 += 8) {
+            const int f = f0 + wave;  // forward-transform task: gate f / ROWS, digit row f % ROWS
+            if (f < FFTS) {
+                const int g = f / ROWS, r = f % ROWS;
+                const int ai = g ? ai1 : ai0;
+                if (ai != 0) {
+                    uint32_t t[16];
+                    cplx z[8];
+                    load_rotated16_hi(lane, sAcc[g] + (r / L) * 1024, ai & 2047, offset, t);
+                    digits_to_z(t, (r % L) + 1, Bgbit, z);
+                    cplx *slot = sSpec + f * 512;  // transposes run inside the task's own, not yet published, spectrum slot
+                    wave_fft_fwd_s(lane, z, slot, sT1, w64);
+                    wave_sync();
+#pragma unroll
+                    for (int m = 0; m < 8; m++) slot[m * 64 + lane] = z[m];
+                }
+            }
+        }
+        cplx B[PRE][8];
+#pragma unroll
+        for (int r = 0; r < PRE; r++) load8(lane, B[r], a.bk + mk_chunk_index(i, r, h, o, ROWS) * 512);
+        __syncthreads();  // spectra published; every rotated read of the accumulators is done
+        cplx S0[8], S1[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) S0[m] = S1[m] = cplx{0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            cplx z[8];
+            if (ai0 != 0) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) z[m] = sSpec[r * 512 + m * 64 + lane];
+                mac8r(S0, z, B[r % PRE]);
+            }
+            if (ai1 != 0) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) z[m] = sSpec[(ROWS + r) * 512 + m * 64 + lane];
+                mac8r(S1, z, B[r % PRE]);
+            }
+            if (r + PRE < ROWS) load8(lane, B[r % PRE], a.bk + mk_chunk_index(i, r + PRE, h, o, ROWS) * 512);
+        }
+        __syncthreads();  // spectra consumed: the area is transpose scratch from here on
+        cplx *xb = sSpec + wave * 512;
+        if (ai0 != 0) {
+            unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[0]) + o * 1024;
+            wave_fft_inv_s(lane, S0, xb, sT1, w64);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int q = lane + 64 * m;
+                atomicAdd(accu + q, (unsigned long long)round_i64(S0[m].re) << (16 * h));
+                atomicAdd(accu + q + 512, (unsigned long long)round_i64(S0[m].im) << (16 * h));
+            }
+        }
+        if (ai1 != 0) {
+            unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[1]) + o * 1024;
+            wave_fft_inv_s(lane, S1, xb, sT1, w64);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int q = lane + 64 * m;
+                atomicAdd(accu + q, (unsigned long long)round_i64(S1[m].re) << (16 * h));
+                atomicAdd(accu + q + 512, (unsigned long long)round_i64(S1[m].im) << (16 * h));
+            }
+        }
+        __syncthreads();  // accumulators updated and scratch free before the next step
+    }
+    if (wave < 2 && (wave == 0 || has1)) extract16_64(lane, sAcc[wave], sAcc[wave] + 1024, a.out + (job0 + wave) * 1025);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // N = 2048 (BASELINE config 5).  Same wave roles as above; every 1024-point transform is a radix-2 split and two twisted
 // 512-point transforms (thfhe_lane.h), so a digit row publishes TWO half spectra (16 KiB) and a phase-2 wave keeps two
 // partial spectra S0 / S1.  LDS at l = 3: T1 tables 16 + accumulator 32 + spectra 96 = 144 KiB, so the transpose buffers
@@ -430,6 +532,7 @@ struct thfhe_mk_ctx {
     int32_t *d_ksk = nullptr;
     cplx *d_tw = nullptr;
     int row_words = 0, w_pad = 0, words = 0, log2_2n = 11;
+    long pair_threshold = 256;  // batches of more rotations than this run two gates per workgroup (mk_blind_rotate_pair_kernel)
     size_t cap_jobs = 0;
     int32_t *d_bara = nullptr, *d_barb = nullptr, *d_u = nullptr, *d_tmp = nullptr;
     size_t cap_stage = 0;
@@ -508,6 +611,16 @@ int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a) {
         case 2: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<2>, grid, block, 0, c->stream, a); break;
         case 3: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<3>, grid, block, 0, c->stream, a); break;
         default: return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 2048 needs decomposition length l <= 3");
+        }
+        THFHE_HIP(hipGetLastError());
+        return THFHE_OK;
+    }
+    if (!a.acc_in && !a.acc_out && c->p.l <= 3 && a.jobs > c->pair_threshold) {  // throughput path: two gates per workgroup
+        const dim3 pgrid((unsigned)((a.jobs + 1) / 2));
+        switch (c->p.l) {
+        case 1: hipLaunchKernelGGL(mk_blind_rotate_pair_kernel<1>, pgrid, block, 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL(mk_blind_rotate_pair_kernel<2>, pgrid, block, 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(mk_blind_rotate_pair_kernel<3>, pgrid, block, 0, c->stream, a); break;
         }
         THFHE_HIP(hipGetLastError());
         return THFHE_OK;
@@ -808,6 +921,12 @@ int thfhe_mk_prologue_dev(thfhe_mk_ctx *c, int op, int which, const int32_t *d0,
     const dim3 grid((unsigned)((c->p.n + 1 + 255) / 256), (unsigned)count);
     hipLaunchKernelGGL(mk_prologue_slice_kernel, grid, dim3(256), 0, c->stream, d0, d1, d2, L, rec_words, first_word, c->p.n, c->log2_2n, (long)count, d_bara, d_barb);
     THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+int thfhe_mk_set_pair_threshold(thfhe_mk_ctx *c, long max_single_jobs) {
+    if (!c || max_single_jobs < 0) return thfhe_fail(THFHE_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->pair_threshold = max_single_jobs;
     return THFHE_OK;
 }
 int thfhe_mk_set_stream(thfhe_mk_ctx *c, void *hip_stream) {

@@ -88,6 +88,7 @@ SIGNATURES = {
     "thfhe_mk_bootstrap": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_prologue_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_size_t]),
     "thfhe_mk_set_stream": (C.c_int, [_vp, _vp]),
+    "thfhe_mk_set_pair_threshold": (C.c_int, [_vp, C.c_long]),
     "thfhe_mk_rotate_partial_dev": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_size_t]),
     "thfhe_mk_extract_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "thfhe_mk_keyswitch_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -375,6 +376,10 @@ class MKCloudKey:
 
     def set_profiling(self, on):
         _check(lib().thfhe_mk_set_profiling(self.h, int(bool(on))))
+
+    def set_pair_threshold(self, max_single_jobs):
+        """Batches of <= max_single_jobs rotations run one gate per workgroup; larger ones two gates per workgroup."""
+        _check(lib().thfhe_mk_set_pair_threshold(self.h, int(max_single_jobs)))
 
     def last_timings(self):
         ms = (C.c_float * 4)()
