@@ -152,6 +152,23 @@ int thfhe_mk_sync(thfhe_mk_ctx *ctx);
 int thfhe_mk_set_profiling(thfhe_mk_ctx *ctx, int enabled);
 int thfhe_mk_last_timings(thfhe_mk_ctx *ctx, float ms[4]);
 
+/* ---- LWE -> TLWE conversion and threshold partial / final decryption: the step after the gate path in the reference's C++
+ * applications.  k = 1, N = 1024; all pointers are HOST arrays.
+ *   thfhe_tlwe_from_lwe     <- TLweFromLwe(ring_cipher, cipher, tlwe_params)       src/libthfhe.cpp:340-348, src/KNN_medical_data.cpp:492-500
+ *                              lwe int32[count][N+1] -> tlwe_a int32[count][N] (a'[0] = a[0], a'[i] = -a[N-i]), tlwe_b int32[count][N] (b'[0] = b)
+ *   thfhe_partial_decrypt   <- ThFHEKeyShare::PartialDecrypt / partialDecrypt       src/libthfhe.cpp:270-293, src/threshold_decryption_functions.cpp:441-480
+ *                              partial[c] = key_share (*) tlwe_a[c] + noise[c]; (*) exact negacyclic product mod 2^32 (torusPolynomialAddMulR);
+ *                              key_share int32[N] with |s| <= 512; noise (the caller's smudging Gaussian) may be NULL
+ *   thfhe_final_decrypt     <- finalDecrypt                                          src/libthfhe.cpp:296-315
+ *                              result[c] = tlwe_b[c] - partials[0][c] + sum_{i>=1} partials[i][c]; bits[c] = result[c][0] > 0; result may be NULL */
+typedef struct thfhe_poly_ctx thfhe_poly_ctx;
+int thfhe_poly_ctx_create(int device, int N, thfhe_poly_ctx **out);
+void thfhe_poly_ctx_destroy(thfhe_poly_ctx *ctx);
+int thfhe_tlwe_from_lwe(thfhe_poly_ctx *ctx, const int32_t *lwe, int32_t *tlwe_a, int32_t *tlwe_b, size_t count);
+int thfhe_partial_decrypt(thfhe_poly_ctx *ctx, const int32_t *key_share, const int32_t *tlwe_a, const int32_t *noise, int32_t *partial, size_t count);
+int thfhe_final_decrypt(thfhe_poly_ctx *ctx, const int32_t *tlwe_b, const int32_t *partials /*[t][count][N]*/, int t, int32_t *result, int32_t *bits,
+                        size_t count);
+
 #ifdef __cplusplus
 }
 #endif

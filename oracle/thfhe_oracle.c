@@ -898,3 +898,33 @@ void oracle_mk_lwe_encrypt(const int32_t *keys, int32_t n, int32_t P, int32_t mu
     oracle_lwe_encrypt(keys, n * P, mu, sigma, seed, idx, rec);
 }
 int32_t oracle_mk_lwe_phase(const int32_t *keys, int32_t n, int32_t P, const int32_t *rec) { return oracle_lwe_phase(keys, n * P, rec); }
+
+/* ============================================================================================
+ * LWE -> TLWE conversion and threshold partial / final decryption  (k = 1)
+ * ========================================================================================== */
+/* TLweFromLwe, src/libthfhe.cpp:340-348 (same in src/KNN_medical_data.cpp:492-500): LWE of dimension N -> ring sample */
+void oracle_tlwe_from_lwe(const int32_t *lwe /*[N+1]*/, int32_t N, int32_t *tlwe_a /*[N]*/, int32_t *tlwe_b /*[N]*/) {
+    tlwe_a[0] = lwe[0];
+    for (int i = 1; i < N; i++) tlwe_a[i] = (int32_t)(0u - (uint32_t)lwe[N - i]);
+    memset(tlwe_b, 0, sizeof(int32_t) * (size_t)N);
+    tlwe_b[0] = lwe[N];
+}
+/* ThFHEKeyShare::PartialDecrypt, src/libthfhe.cpp:270-293: partial = key_share (*) a + smudging noise
+ * (torusPolynomialAddMulR = exact negacyclic product mod 2^32; the Gaussian noise is an input here) */
+void oracle_partial_decrypt(const int32_t *key_share, const int32_t *tlwe_a, const int32_t *noise /* NULL = none */, int32_t N,
+                            int32_t *partial) {
+    oracle_polymul_schoolbook32(key_share, tlwe_a, N, partial);
+    if (noise)
+        for (int j = 0; j < N; j++) partial[j] = (int32_t)((uint32_t)partial[j] + (uint32_t)noise[j]);
+}
+/* finalDecrypt, src/libthfhe.cpp:296-315: result = b - partial_0 + sum_{i>=1} partial_i ; message bit = result[0] > 0 */
+int32_t oracle_final_decrypt(const int32_t *tlwe_b, const int32_t *partials /*[t][N]*/, int32_t t, int32_t N, int32_t *result /*[N] or NULL*/) {
+    int32_t r0 = 0;
+    for (int j = 0; j < N; j++) {
+        uint32_t v = (uint32_t)tlwe_b[j];
+        for (int i = 0; i < t; i++) v = i == 0 ? v - (uint32_t)partials[(size_t)i * N + j] : v + (uint32_t)partials[(size_t)i * N + j];
+        if (result) result[j] = (int32_t)v;
+        if (j == 0) r0 = (int32_t)v;
+    }
+    return r0 > 0 ? 1 : 0;
+}

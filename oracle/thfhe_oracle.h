@@ -110,6 +110,11 @@ void oracle_mk_lwe_encrypt(const int32_t *keys /*[P][n]*/, int32_t n, int32_t P,
                            uint64_t seed, uint64_t idx, int32_t *rec);
 int32_t oracle_mk_lwe_phase(const int32_t *keys, int32_t n, int32_t P, const int32_t *rec);
 
+/* ---- LWE -> TLWE conversion, threshold partial / final decryption (k = 1)   src/libthfhe.cpp:270-348 ---- */
+void oracle_tlwe_from_lwe(const int32_t *lwe /*[N+1]*/, int32_t N, int32_t *tlwe_a /*[N]*/, int32_t *tlwe_b /*[N]*/);
+void oracle_partial_decrypt(const int32_t *key_share, const int32_t *tlwe_a, const int32_t *noise, int32_t N, int32_t *partial);
+int32_t oracle_final_decrypt(const int32_t *tlwe_b, const int32_t *partials /*[t][N]*/, int32_t t, int32_t N, int32_t *result);
+
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

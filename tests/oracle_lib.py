@@ -107,6 +107,9 @@ def lib():
         "oracle_keygen_mk": (None, [PP, C.c_uint64, C.c_double, C.c_double, i32p, i64p, i64p, i32p]),
         "oracle_lwe_encrypt": (None, [i32p, C.c_int32, C.c_int32, C.c_double, C.c_uint64, C.c_uint64, i32p]),
         "oracle_lwe_phase": (C.c_int32, [i32p, C.c_int32, i32p]),
+        "oracle_tlwe_from_lwe": (None, [i32p, C.c_int32, i32p, i32p]),
+        "oracle_partial_decrypt": (None, [i32p, i32p, i32p, C.c_int32, i32p]),
+        "oracle_final_decrypt": (C.c_int32, [i32p, i32p, C.c_int32, C.c_int32, i32p]),
         "oracle_max_threads": (C.c_int, []),
     }
     for name, (res, args) in sig.items():

@@ -608,7 +608,7 @@ void thfhe_ctx_destroy(thfhe_ctx *c) {
     (void)hipFree(c->d_bara);
     (void)hipFree(c->d_barb);
     (void)hipFree(c->d_u);
-    for (auto &p : c->d_in) hipFree(p);
+    for (auto &p : c->d_in) (void)hipFree(p);
     (void)hipFree(c->d_out);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);

@@ -81,6 +81,11 @@ SIGNATURES = {
     "thfhe_set_coop_threshold": (C.c_int, [_vp, C.c_int]),
     "thfhe_set_profiling": (C.c_int, [_vp, C.c_int]),
     "thfhe_last_timings": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "thfhe_poly_ctx_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "thfhe_poly_ctx_destroy": (None, [_vp]),
+    "thfhe_tlwe_from_lwe": (C.c_int, [_vp, _i32p, _i32p, _i32p, C.c_size_t]),
+    "thfhe_partial_decrypt": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
+    "thfhe_final_decrypt": (C.c_int, [_vp, _i32p, _i32p, C.c_int, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_ctx_create": (C.c_int, [C.POINTER(Params), _i64p, _i32p, C.c_int, C.POINTER(_vp)]),
     "thfhe_mk_ctx_destroy": (None, [_vp]),
     "thfhe_mk_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
