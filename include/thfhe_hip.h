@@ -83,6 +83,15 @@ int thfhe_gates(thfhe_ctx *ctx, int op, const int32_t *in0, const int32_t *in1, 
 /* One launch for a level of a gate DAG: gate g applies ops[g] (any two-input bootstrapped gate NAND..ORYN) to
  * (in0[g], in1[g]).  ops is a HOST array of `count` opcodes. */
 int thfhe_gates_mixed(thfhe_ctx *ctx, const int32_t *ops, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count);
+/* Gate-DAG evaluation: the levelising scheduler + device-resident executor for the reference's circuits (FullAdder / difference /
+ * distance / sort_with_distance ..., src/KNN_medical_data.cpp:127-489, issued there as sequential boots* calls).
+ *   wires  HOST table int32[n_inputs + n_gates][n+1]: rows [0, n_inputs) hold the input ciphertexts, row n_inputs + g receives gate g
+ *   gates  HOST int32[n_gates][4] = (opcode, in0, in1, in2), topological order, operands are earlier wire ids (unused = -1);
+ *          opcodes: the two-input bootstrapped gates, THFHE_MUX, THFHE_NOT, THFHE_COPY
+ * Gates are scheduled ASAP into levels; each level is ONE blind-rotate launch per gate class (two-input with per-gate opcodes, MUX);
+ * the wire table stays in HBM and the host is not synchronised between levels.
+ * stats (optional) int64[4] = {levels, bootstrap launches, blind rotations, widest level}. */
+int thfhe_dag_run(thfhe_ctx *ctx, int32_t *wires, size_t n_inputs, const int32_t *gates, size_t n_gates, int64_t *stats);
 int thfhe_bootstrap(thfhe_ctx *ctx, int32_t mu, const int32_t *x, int32_t *out, size_t count);
 int thfhe_bootstrap_wo_keyswitch(thfhe_ctx *ctx, int32_t mu, const int32_t *x, int32_t *out_N1, size_t count);
 int thfhe_keyswitch(thfhe_ctx *ctx, const int32_t *in_N1, int32_t *out, size_t count);

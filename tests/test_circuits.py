@@ -204,4 +204,15 @@ def test_reduced_knn_decision_on_gpu():
     assert [from_bits(K.decrypt(vals[w])) for w in sdists] == d
     assert from_bits(K.decrypt(vals[count])) == 2 and bool(K.decrypt(vals[[decision]])[0])
     assert stats["launches"] < stats["gates"] / 4                      # levelised: far fewer launches than gates
+    # the native scheduler / device-resident executor (thfhe_dag_run) and the host-driven level loop evaluate the same gates
+    assert np.array_equal(vals, Cc.evaluate_levels(ck, cir, K.encrypt(np.array(plain), seed=5)))
+    # NOT / COPY gates ride on their operand's level (no bootstrap), including NOT of an input and NOT of a NOT
+    c2 = Cc.Circuit()
+    x, y = c2.inputs(1)[0], c2.inputs(1)[0]
+    nx = c2.gate(thfhe.NOT, x); nnx = c2.gate(thfhe.NOT, nx); g1 = c2.gate(thfhe.NAND, nnx, y); ng = c2.gate(thfhe.NOT, g1)
+    g2 = c2.gate(thfhe.MUX, ng, x, y); cp = c2.gate(thfhe.COPY, g2)
+    for bits in ([0, 0], [0, 1], [1, 0], [1, 1]):
+        v = Cc.evaluate(ck, c2, K.encrypt(np.array(bits), seed=9))
+        assert np.array_equal(K.decrypt(v), Cc.simulate_ext(c2, bits))
+        assert np.array_equal(v, Cc.evaluate_levels(ck, c2, K.encrypt(np.array(bits), seed=9)))
     ck.close()

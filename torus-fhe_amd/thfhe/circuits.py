@@ -11,7 +11,7 @@ src/bootstrap_modules.cpp:95).
 """
 import numpy as np
 
-from . import AND, MUX, NOT, OR, XOR
+from . import AND, COPY, MUX, NOT, OR, XOR
 
 
 class Circuit:
@@ -41,18 +41,18 @@ class Circuit:
         lv = {}
         for gi, (op, a, b, c) in enumerate(self.gates):
             d = max(depth[w] for w in (a, b, c) if w >= 0)
-            if op != NOT:
+            if op not in (NOT, COPY):
                 d += 1
             depth[self.n_inputs + gi] = d
-            lv.setdefault((int(d), op == NOT), []).append(gi)
+            lv.setdefault((int(d), op in (NOT, COPY)), []).append(gi)
         keys = sorted(lv)  # (depth, is_not): bootstrapped gates of depth d first, then the free NOTs that read them
         return [lv[k] for k in keys]
 
     def census(self):
         ops = [g[0] for g in self.gates]
-        boot = sum(1 for o in ops if o not in (NOT,))
+        boot = sum(1 for o in ops if o not in (NOT, COPY))
         return dict(gates=len(ops), bootstrapped=boot, mux=ops.count(MUX), rotations=boot + ops.count(MUX),
-                    depth=len([l for l in self.levels() if self.gates[l[0]][0] != NOT]))
+                    depth=len([l for l in self.levels() if self.gates[l[0]][0] not in (NOT, COPY)]))
 
 
 # ---- the reference's building blocks (src/KNN_medical_data.cpp) ---------------------------------------------------
@@ -190,6 +190,8 @@ def simulate(cir, input_bits):
         o = cir.n_inputs + gi
         if op == NOT:
             v[o] = not v[a]
+        elif op == COPY:
+            v[o] = v[a]
         elif op == MUX:
             v[o] = v[b] if v[a] else v[c]
         else:
@@ -197,9 +199,24 @@ def simulate(cir, input_bits):
     return v
 
 
+simulate_ext = simulate
+
+
 # ---- evaluator --------------------------------------------------------------------------------------------------------
 def evaluate(ck, cir, input_records, stats=None):
-    """Run the DAG on the engine.  input_records: int32[n_inputs][n+1].  Returns int32[n_wires][n+1]."""
+    """Run the DAG on the engine.  input_records: int32[n_inputs][n+1].  Returns int32[n_wires][n+1].
+    Single-key contexts use the native scheduler / executor (thfhe_dag_run: wires stay in HBM, no host round trip per level);
+    multi-key contexts go level by level through thfhe_mk_gates_mixed (evaluate_levels)."""
+    if hasattr(ck, "dag_run"):
+        vals, st = ck.dag_run(input_records, np.array(cir.gates, np.int32).reshape(-1, 4))
+        if stats is not None:
+            stats.update(cir.census(), **st)
+        return vals
+    return evaluate_levels(ck, cir, input_records, stats)
+
+
+def evaluate_levels(ck, cir, input_records, stats=None):
+    """The same schedule driven from the host: one host-buffer call per level (works for single-key and multi-key contexts)."""
     words = ck.words
     vals = np.zeros((cir.n_wires(), words), np.int32)
     vals[:cir.n_inputs] = np.asarray(input_records, np.int32).reshape(cir.n_inputs, words)
@@ -208,9 +225,10 @@ def evaluate(ck, cir, input_records, stats=None):
     launches = 0
     for level in cir.levels():
         op0 = gates[level[0]][0]
-        if op0 == NOT:
+        if op0 in (NOT, COPY):
             for g in level:   # in gate order: a NOT may read another NOT of the same depth
-                vals[base + g] = (0 - vals[gates[g][1]].astype(np.int64)).astype(np.int32)
+                src = vals[gates[g][1]]
+                vals[base + g] = (0 - src.astype(np.int64)).astype(np.int32) if gates[g][0] == NOT else src
             continue
         two = [g for g in level if gates[g][0] != MUX]
         mux = [g for g in level if gates[g][0] == MUX]
