@@ -190,11 +190,14 @@ def main():
                                f"(P={p.parties}, n={p.n}, N={p.N}, k={p.k}, l={p.l}, Bgbit={p.Bgbit}, ks {p.ks_t}/{p.ks_basebit}), keys+ciphertexts resident in HBM",
                    "gates_per_gpu_per_step": B, "param_set": args.set, "parallelism": f"gate-batch sharding x{world}, replicated keys",
                    "timing_backend": backend},
-        "roofline": {"bound": "hbm", "kernel": (f"mk_blind_rotate_coop{'2k' if p.N == 2048 else ''}_kernel<{p.l}>" if mk else f"sk_blind_rotate_ring_kernel<{p.l}>"),
+        "roofline": {"bound": "hbm", "kernel": (("mk_blind_rotate_coop2k_kernel" if p.N == 2048 else
+                                 ("mk_blind_rotate_pair_kernel" if (p.l <= 3 and B > 256) else "mk_blind_rotate_coop_kernel")) + f"<{p.l}>") if mk
+                               else (f"sk_blind_rotate_ring_kernel<{p.l}>" if B > 1024 else f"sk_blind_rotate_coop_kernel<{p.l}>"),
                      "achieved": br_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": br_achieved / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": br_bytes, "avg_launch_ms": br_avg_ms,
-                     "note": "algorithmic bytes count the whole transformed key once per gate (SURVEY.md 8d); the kernel streams it once per "
-                             "8-gate workgroup out of L2/Infinity Cache, so frac is not bounded by 1 (measured HBM traffic: profiles/)",
+                     "note": "algorithmic bytes count the whole transformed key once per gate (SURVEY.md 8d); the kernels share every key chunk between "
+                             "the gates of a workgroup (8 single-key / 2 multi-key) and all workgroups hit L2/Infinity Cache, so frac is not bounded by 1 "
+                             "(measured HBM traffic: profiles/)",
                      "keyswitch_avg_launch_ms": float(np.mean(ks_ms)),
                      "whole_gate": {"bytes_per_gate": ab["total"],
                                     "achieved": value / world * ab["total"] / 1e9,

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): rocprofv3 kernel trace + separate PMC passes of the default bench workload.
-# usage: tools/profile_bench.sh <tag>   -> gpurun_out/<tag>_{trace,fetch,write,sq,lds,tcc}/...
+# usage: tools/profile_bench.sh <tag> [bench.py args, e.g. --set MK2 --batch 1024]   -> gpurun_out/<tag>_{trace,fetch,write,sq,lds,tcc}/...
 set -e
 TAG=${1:-r01}
+shift || true
+EXTRA="$@"
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline"
+B="python3 $R/bench.py --no-cpu-baseline $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- $B --steps 10 --warmup 2 > $OUT/${TAG}_trace.json 2> $OUT/${TAG}_trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- $B --steps 3 --warmup 1 > $OUT/${TAG}_fetch.json 2> $OUT/${TAG}_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- $B --steps 3 --warmup 1 > $OUT/${TAG}_write.json 2> $OUT/${TAG}_write.err

@@ -12,7 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
-lines = [f"# rocprofv3 summary `{tag}` — `python3 bench.py --no-cpu-baseline` (4096 NAND / step, SK-128, 1x MI355X)\n"]
+workload, batch, alg_mb = "4096 NAND / step, SK-128", 4096, 61.9
+try:   # the bench line of the traced run names the workload
+    _j = json.loads(open(os.path.join(G, f"{tag}_trace.json")).read().strip().splitlines()[-1])
+    batch = _j["config"]["gates_per_gpu_per_step"]
+    workload = f"{batch} NAND / step, {_j['config']['param_set']}"
+    alg_mb = _j["roofline"]["algorithmic_bytes_per_launch"] / batch / 1e6
+except Exception:
+    pass
+lines = [f"# rocprofv3 summary `{tag}` — `python3 bench.py --no-cpu-baseline ...` ({workload}, 1x MI355X)\n"]
 
 
 def find(pattern):
@@ -68,8 +76,8 @@ for k in fetch:
         wv = sorted(write.get(k, {}).get("WRITE_SIZE", [0]))[-3:]
         f_kb, w_kb = sum(fv) / len(fv), sum(wv) / len(wv)
         traffic = (2 * f_kb + w_kb) * 1024
-        lines.append(f"**HBM traffic of one blind-rotate launch (4096 gates)**: FETCH_SIZE = {f_kb:.0f} KB (x2 gfx950 correction for 16-B/lane "
+        lines.append(f"**HBM traffic of one blind-rotate launch ({batch} gates)**: FETCH_SIZE = {f_kb:.0f} KB (x2 gfx950 correction for 16-B/lane "
                      f"coalesced reads -> {2*f_kb*1024/1e6:.1f} MB), WRITE_SIZE = {w_kb:.0f} KB -> **{traffic/1e6:.1f} MB per launch** "
-                     f"= {traffic/4096/1e3:.1f} KB per gate (algorithmic: 61.9 MB per gate; the key stays in L2 / Infinity Cache).\n")
+                     f"= {traffic/batch/1e3:.1f} KB per gate (algorithmic: {alg_mb:.1f} MB per gate; the key stays in L2 / Infinity Cache).\n")
 open(os.path.join(P, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
