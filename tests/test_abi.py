@@ -74,3 +74,30 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".h", ".hip", ".cpp", ".jl")) or fn == "Makefile":
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "oracle_lib" not in txt and "thfhe_oracle" not in txt and "lane_emu" not in txt.replace("tests/emu/lane_emu.cpp", ""), os.path.join(dp, fn)
+
+
+def test_new_entry_points_validate_arguments_without_a_device():
+    # party-sharded blocks, DAG executor, threshold decryption, N = 2048: argument checks run before any device work
+    import thfhe
+    L = thfhe.lib()
+    h = C.c_void_p()
+    assert L.thfhe_dag_run(None, None, 0, None, 0, None) == -1
+    assert L.thfhe_mk_set_pair_threshold(None, 0) == -1 and L.thfhe_mk_set_stream(None, None) == -1
+    assert L.thfhe_mk_rotate_partial_dev(None, None, None, 0, None, None, 1) == -1
+    assert L.thfhe_mk_prologue_dev(None, 0, 0, None, None, None, 0, 0, None, None, 1) == -1
+    assert L.thfhe_partial_decrypt(None, None, None, None, None, 1) == -1 and L.thfhe_final_decrypt(None, None, None, 0, None, None, 1) == -1
+    assert L.thfhe_poly_ctx_create(0, 512, C.byref(h)) == -2 and b"N = 1024" in L.thfhe_last_error()
+    z64, z32 = np.zeros(8, np.int64), np.zeros(8, np.int32)
+    p64, p32 = z64.ctypes.data_as(C.POINTER(C.c_int64)), z32.ctypes.data_as(C.POINTER(C.c_int32))
+    # N = 2048 is a multi-key ring degree only, and only up to l = 3
+    rc = L.thfhe_mk_ctx_create(C.byref(thfhe.make_params("MK4-N2048", l=4, Bgbit=4)), p64, p32, 0, C.byref(h))
+    assert rc == -2 and b"l <= 3" in L.thfhe_last_error()
+    rc = L.thfhe_mk_ctx_create(C.byref(thfhe.make_params("MK4", N=4096)), p64, p32, 0, C.byref(h))
+    assert rc == -2
+    if L.thfhe_device_count() == 0:
+        rc = L.thfhe_mk_ctx_create(C.byref(thfhe.make_params("MK4-N2048")), p64, p32, 0, C.byref(h))
+        assert rc == -3 and b"no usable HIP device" in L.thfhe_last_error()
+        assert L.thfhe_poly_ctx_create(0, 1024, C.byref(h)) == -3
+        with pytest.raises(thfhe.ThfheError):
+            from thfhe import threshold
+            threshold.PolyContext(0)
