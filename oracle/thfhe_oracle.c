@@ -928,3 +928,235 @@ int32_t oracle_final_decrypt(const int32_t *tlwe_b, const int32_t *partials /*[t
     }
     return r0 > 0 ? 1 : 0;
 }
+
+/* ============================================================================================
+ * CCS multi-key scheme (Chen-Chillotti-Song): mk_bootstrap / mk_gate_nand of the reference      
+ *   MKRLweSample acc = (a_0 .. a_{P-1}, b), Torus32        J/mk_internals.jl:104-152
+ *   UniProduct_old                                        J/mk_internals.jl:477-536
+ *   mk_mux_rotate / mk_blind_rotate / mk_bootstrap         J/mk_internals.jl:805-858
+ *   mk_rlwe_extract_sample :141-148, mk_keyswitch :714-728, mk_gate_nand J/mk_gates.jl:7-13
+ * Key tables (coefficient domain, Torus32):
+ *   bk  int32[P][n][3][l][N]   per (party, j): d1[l], f0[l], f1[l] of MKTGswUESample (:338-388; c0, c1, d0 are not used by UniProduct_old)
+ *   pk  int32[P][l][N]         PublicKey.b (:209-245);   crs int32[l][N]  SharedKey.a (:156-168)
+ *   ksk int32[P][N][t][base-1][n+1]
+ * Records: MK LWE int32[P*n+1]; extracted sample int32[P*N+1] = a[p*N + j], b.
+ * ========================================================================================== */
+struct oracle_ccs_ctx {
+    oracle_params p;
+    const int32_t *bk, *pk, *crs, *ksk; /* borrowed */
+    uint64_t *bk_ntt, *pk_ntt, *crs_ntt;
+};
+static void ccs_ntt_table(const int32_t *src, size_t npolys, int N, uint64_t *dst) {
+    const gl_tables *T = gl_get_tables(N);
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)npolys; q++) {
+        for (int j = 0; j < N; j++) dst[(size_t)q * N + j] = gl_from_i64(src[(size_t)q * N + j]);
+        gl_ntt_fwd(dst + (size_t)q * N, T);
+    }
+}
+oracle_ccs_ctx *oracle_ccs_ctx_create(const oracle_params *p, const int32_t *bk, const int32_t *pk, const int32_t *crs, const int32_t *ksk) {
+    if (p->torus_bits != 32 || p->k != 1) return NULL;
+    oracle_ccs_ctx *c = (oracle_ccs_ctx *)calloc(1, sizeof(*c));
+    c->p = *p;
+    c->bk = bk, c->pk = pk, c->crs = crs, c->ksk = ksk;
+    const size_t nb = (size_t)p->parties * p->n * 3 * p->l, np = (size_t)p->parties * p->l, nc = (size_t)p->l;
+    c->bk_ntt = (uint64_t *)malloc(sizeof(uint64_t) * (nb + np + nc) * p->N);
+    c->pk_ntt = c->bk_ntt + nb * p->N;
+    c->crs_ntt = c->pk_ntt + np * p->N;
+    ccs_ntt_table(bk, nb, p->N, c->bk_ntt);
+    ccs_ntt_table(pk, np, p->N, c->pk_ntt);
+    ccs_ntt_table(crs, nc, p->N, c->crs_ntt);
+    return c;
+}
+void oracle_ccs_ctx_destroy(oracle_ccs_ctx *c) {
+    if (!c) return;
+    free(c->bk_ntt);
+    free(c);
+}
+/* out = sum_l digits[l] (*) key[l], exact mod 2^32; dig_ntt: the digits' NTTs (shared by several products) */
+static void ccs_dot(const oracle_ccs_ctx *c, const int32_t *digits, const uint64_t *dig_ntt, const int32_t *key, const uint64_t *key_ntt,
+                    int use_schoolbook, int32_t *out) {
+    const int N = c->p.N, l = c->p.l;
+    if (use_schoolbook) {
+        int32_t *prod = (int32_t *)malloc(sizeof(int32_t) * N);
+        memset(out, 0, sizeof(int32_t) * N);
+        for (int q = 0; q < l; q++) {
+            oracle_polymul_schoolbook32(digits + (size_t)q * N, key + (size_t)q * N, N, prod);
+            for (int j = 0; j < N; j++) out[j] = (int32_t)((uint32_t)out[j] + (uint32_t)prod[j]);
+        }
+        free(prod);
+        return;
+    }
+    const gl_tables *T = gl_get_tables(N);
+    uint64_t *acc = (uint64_t *)malloc(sizeof(uint64_t) * N);
+    for (int j = 0; j < N; j++) {
+        uint64_t s = 0;
+        for (int q = 0; q < l; q++) s = gl_add(s, gl_mul(dig_ntt[(size_t)q * N + j], key_ntt[(size_t)q * N + j]));
+        acc[j] = s;
+    }
+    gl_ntt_inv(acc, T);
+    for (int j = 0; j < N; j++) out[j] = (int32_t)(uint32_t)(uint64_t)gl_to_centered(acc[j]);
+    free(acc);
+}
+static void ccs_decompose_all(const oracle_ccs_ctx *c, const int32_t *polys /*[P+1][N]*/, int32_t *dig /*[P+1][l][N]*/, uint64_t *dig_ntt) {
+    const int N = c->p.N, l = c->p.l, P = c->p.parties;
+    const gl_tables *T = gl_get_tables(N);
+    for (int i = 0; i <= P; i++) {
+        oracle_decompose32(polys + (size_t)i * N, N, l, c->p.Bgbit, dig + (size_t)i * l * N);
+        for (int q = 0; q < l; q++) {
+            uint64_t *d = dig_ntt + ((size_t)i * l + q) * N;
+            for (int j = 0; j < N; j++) d[j] = gl_from_i64(dig[((size_t)i * l + q) * N + j]);
+            gl_ntt_fwd(d, T);
+        }
+    }
+}
+/* UniProduct_old(acc, bk[j, party], pk, crs, party)      J/mk_internals.jl:477-536 ; acc, out: int32[P+1][N] (a_0..a_{P-1}, b) */
+void oracle_ccs_uniproduct(const oracle_ccs_ctx *c, int32_t party, int32_t j, const int32_t *acc, int32_t *out, int use_schoolbook) {
+    const int N = c->p.N, l = c->p.l, P = c->p.parties, n = c->p.n;
+    const size_t G = (size_t)(P + 1) * l * N;
+    int32_t *dig = (int32_t *)malloc(sizeof(int32_t) * (G + (size_t)(P + 2) * N));
+    int32_t *v = dig + G, *w = v + (size_t)(P + 1) * N;
+    uint64_t *dn = (uint64_t *)malloc(sizeof(uint64_t) * G);
+    const size_t ue = (((size_t)party * n + j) * 3) * l * N; /* d1 | f0 | f1 */
+    const int32_t *d = c->bk + ue, *f0 = d + (size_t)l * N, *f1 = f0 + (size_t)l * N;
+    const uint64_t *dN = c->bk_ntt + ue, *f0N = dN + (size_t)l * N, *f1N = f0N + (size_t)l * N;
+    ccs_decompose_all(c, acc, dig, dn);
+    for (int i = 0; i <= P; i++) { /* u_i (i < P), u0 (i = P) ; v_i, v0 */
+        const int32_t *di = dig + (size_t)i * l * N;
+        const uint64_t *dni = dn + (size_t)i * l * N;
+        ccs_dot(c, di, dni, d, dN, use_schoolbook, out + (size_t)i * N);
+        if (i < P) {
+            ccs_dot(c, di, dni, c->pk + (size_t)i * l * N, c->pk_ntt + (size_t)i * l * N, use_schoolbook, v + (size_t)i * N);
+        } else {
+            ccs_dot(c, di, dni, c->crs, c->crs_ntt, use_schoolbook, v + (size_t)i * N);
+            for (int t = 0; t < N; t++) v[(size_t)i * N + t] = (int32_t)(0u - (uint32_t)v[(size_t)i * N + t]); /* v0 = -sum dec_b * a */
+        }
+    }
+    ccs_decompose_all(c, v, dig, dn); /* g^{-1}(v_i), g^{-1}(v0) */
+    for (int i = 0; i <= P; i++) {
+        const int32_t *di = dig + (size_t)i * l * N;
+        const uint64_t *dni = dn + (size_t)i * l * N;
+        ccs_dot(c, di, dni, f0, f0N, use_schoolbook, w); /* w0_i : into b */
+        for (int t = 0; t < N; t++) out[(size_t)P * N + t] = (int32_t)((uint32_t)out[(size_t)P * N + t] + (uint32_t)w[t]);
+        ccs_dot(c, di, dni, f1, f1N, use_schoolbook, w); /* w1_i : into a[party] */
+        for (int t = 0; t < N; t++) out[(size_t)party * N + t] = (int32_t)((uint32_t)out[(size_t)party * N + t] + (uint32_t)w[t]);
+    }
+    free(dig);
+    free(dn);
+}
+/* mk_mux_rotate: acc += UniProduct(X^barai acc - acc)      J/mk_internals.jl:805-812 */
+void oracle_ccs_mux_rotate(const oracle_ccs_ctx *c, int32_t party, int32_t j, int32_t barai, int32_t *acc, int use_schoolbook) {
+    const int N = c->p.N, P = c->p.parties;
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)(P + 1) * N), *up = tmp + (size_t)(P + 1) * N;
+    for (int m = 0; m <= P; m++) {
+        oracle_mul_by_monomial32(acc + (size_t)m * N, barai, N, tmp + (size_t)m * N);
+        for (int q = 0; q < N; q++) tmp[(size_t)m * N + q] = (int32_t)((uint32_t)tmp[(size_t)m * N + q] - (uint32_t)acc[(size_t)m * N + q]);
+    }
+    oracle_ccs_uniproduct(c, party, j, tmp, up, use_schoolbook);
+    for (size_t q = 0; q < (size_t)(P + 1) * N; q++) acc[q] = (int32_t)((uint32_t)acc[q] + (uint32_t)up[q]);
+    free(tmp);
+}
+/* mk_bootstrap_wo_keyswitch: x int32[P*n+1] -> out int32[P*N+1]      J/mk_internals.jl:815-852 */
+void oracle_ccs_bootstrap_wo_keyswitch(const oracle_ccs_ctx *c, int32_t mu, const int32_t *x, int32_t *out, int use_schoolbook) {
+    const int N = c->p.N, n = c->p.n, P = c->p.parties;
+    int32_t barb = oracle_modswitch(x[(size_t)n * P], N);
+    int32_t *acc = (int32_t *)calloc((size_t)(P + 1) * N, sizeof(int32_t));
+    int32_t *tv = (int32_t *)malloc(sizeof(int32_t) * N);
+    for (int j = 0; j < N; j++) tv[j] = mu;
+    oracle_mul_by_monomial32(tv, -barb, N, acc + (size_t)P * N);
+    for (int p = 0; p < P; p++)
+        for (int j = 0; j < n; j++) {
+            int32_t bara = oracle_modswitch(x[(size_t)p * n + j], N);
+            if (bara != 0) oracle_ccs_mux_rotate(c, p, j, bara, acc, use_schoolbook);
+        }
+    for (int p = 0; p < P; p++) { /* mk_rlwe_extract_sample: reverse_polynomial per party */
+        const int32_t *a = acc + (size_t)p * N;
+        out[(size_t)p * N] = a[0];
+        for (int j = 1; j < N; j++) out[(size_t)p * N + j] = (int32_t)(0u - (uint32_t)a[N - j]);
+    }
+    out[(size_t)P * N] = acc[(size_t)P * N];
+    free(tv);
+    free(acc);
+}
+/* mk_keyswitch      J/mk_internals.jl:714-728: party p switches (a[:, p], 0) with ks[p]; b = u.b + sum of the parts' b */
+void oracle_ccs_keyswitch(const oracle_ccs_ctx *c, const int32_t *in, int32_t *out) {
+    const int N = c->p.N, n = c->p.n, P = c->p.parties, t = c->p.ks_t, bb = c->p.ks_basebit;
+    const size_t per_party = (size_t)N * t * ((1 << bb) - 1) * ((size_t)n + 1);
+    int32_t *part = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    uint32_t b = (uint32_t)in[(size_t)P * N];
+    for (int p = 0; p < P; p++) {
+        keyswitch_with(c->ksk + (size_t)p * per_party, N, n, t, bb, in + (size_t)p * N, 0, part);
+        memcpy(out + (size_t)p * n, part, sizeof(int32_t) * n);
+        b += (uint32_t)part[n];
+    }
+    out[(size_t)n * P] = (int32_t)b;
+    free(part);
+}
+/* mk_gate_nand (J/mk_gates.jl:7-13) and, with the same bootstrap, the other two-input linear prologues of J/gates.jl */
+int oracle_ccs_gates(const oracle_ccs_ctx *c, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count, int use_schoolbook) {
+    const int n = c->p.n, N = c->p.N, P = c->p.parties;
+    const size_t rec = (size_t)n * P + 1;
+    lin_t L;
+    if (op == OR_GATE_MUX || op == OR_GATE_NOT || op == OR_GATE_COPY || gate_lin(op, 0, &L) != 0) return -1;
+    int32_t *res = (int32_t *)malloc(sizeof(int32_t) * count * rec);
+#pragma omp parallel for schedule(dynamic)
+    for (long g = 0; g < (long)count; g++) {
+        int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (rec + (size_t)P * N + 1)), *u = tmp + rec;
+        const int32_t *x = in0 + g * rec, *y = in1 + g * rec;
+        for (size_t q = 0; q < rec; q++) tmp[q] = (int32_t)((uint32_t)L.cx * (uint32_t)x[q] + (uint32_t)L.cy * (uint32_t)y[q]);
+        tmp[rec - 1] = (int32_t)((uint32_t)tmp[rec - 1] + (uint32_t)L.cb);
+        oracle_ccs_bootstrap_wo_keyswitch(c, 1 << 29, tmp, u, use_schoolbook);
+        oracle_ccs_keyswitch(c, u, res + g * rec);
+        free(tmp);
+    }
+    memcpy(out, res, sizeof(int32_t) * count * rec);
+    free(res);
+    return 0;
+}
+/* key material: SecretKey / SharedKey / CloudKeyPart (PublicKey, BootstrapKeyPart = mk_tgsw_encrypt of every key bit, KeyswitchKey)
+ * J/mk_api.jl:368-384, J/mk_internals.jl:156-168,209-245,390-448,745-775 -- with OUR random streams */
+void oracle_keygen_ccs(const oracle_params *p, uint64_t seed, double sigma_bk, double sigma_ks, int32_t *lwe_keys /*[P][n]*/, int32_t *rlwe_keys /*[P][N]*/,
+                       int32_t *bk, int32_t *pk, int32_t *crs, int32_t *ksk) {
+    const int n = p->n, N = p->N, l = p->l, P = p->parties;
+    rng_t r;
+    rng_init(&r, seed, 31);
+    for (int i = 0; i < P * n; i++) lwe_keys[i] = (int32_t)(rng_u64(&r) & 1);
+    rng_init(&r, seed, 32);
+    for (int i = 0; i < P * N; i++) rlwe_keys[i] = (int32_t)(rng_u64(&r) & 1); /* RLweKey(rng, params): binary */
+    rng_init(&r, seed, 33);
+    for (int i = 0; i < l * N; i++) crs[i] = (int32_t)(uint32_t)rng_u64(&r); /* SharedKey.a */
+    rng_init(&r, seed, 34);
+    int32_t *prod = (int32_t *)malloc(sizeof(int32_t) * N);
+    for (int q = 0; q < P; q++) /* PublicKey: b_i = s (*) a_i + e_i */
+        for (int i = 0; i < l; i++) {
+            key_mul32(rlwe_keys + (size_t)q * N, crs + (size_t)i * N, N, prod);
+            for (int t = 0; t < N; t++) pk[((size_t)q * l + i) * N + t] = (int32_t)((uint32_t)prod[t] + (uint32_t)dtot32(rng_gauss(&r) * sigma_bk));
+        }
+    free(prod);
+#pragma omp parallel for schedule(dynamic) collapse(2)
+    for (int q = 0; q < P; q++)
+        for (int j = 0; j < n; j++) { /* mk_tgsw_encrypt(lwe_key[j]) -> d1, f0, f1 */
+            rng_t ri;
+            rng_init(&ri, seed, 300000 + (uint64_t)q * 10000 + (uint64_t)j);
+            int32_t *rr = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)N), *pr = rr + N;
+            int32_t *ue = bk + (((size_t)q * n + j) * 3) * l * N, *d1 = ue, *f0 = ue + (size_t)l * N, *f1 = f0 + (size_t)l * N;
+            const uint32_t m = (uint32_t)lwe_keys[(size_t)q * n + j];
+            for (int t = 0; t < N; t++) rr[t] = (int32_t)(rng_u64(&ri) & 1); /* the shared randomness r */
+            for (int i = 0; i < l; i++) {
+                const uint32_t g = 1u << (32 - (i + 1) * p->Bgbit);
+                key_mul32(rr, crs + (size_t)i * N, N, pr);
+                for (int t = 0; t < N; t++) d1[(size_t)i * N + t] = (int32_t)((uint32_t)pr[t] + (uint32_t)dtot32(rng_gauss(&ri) * sigma_bk));
+                d1[(size_t)i * N] = (int32_t)((uint32_t)d1[(size_t)i * N] + m * g);
+                for (int t = 0; t < N; t++) f1[(size_t)i * N + t] = (int32_t)(uint32_t)rng_u64(&ri);
+                key_mul32(rlwe_keys + (size_t)q * N, f1 + (size_t)i * N, N, pr);
+                for (int t = 0; t < N; t++)
+                    f0[(size_t)i * N + t] = (int32_t)((uint32_t)pr[t] + (uint32_t)dtot32(rng_gauss(&ri) * sigma_bk) + (uint32_t)rr[t] * g);
+            }
+            free(rr);
+        }
+    const size_t per_party = (size_t)N * p->ks_t * ((1 << p->ks_basebit) - 1) * ((size_t)n + 1);
+    for (int q = 0; q < P; q++) {
+        rng_init(&r, seed, 40 + (uint64_t)q);
+        gen_ksk(&r, rlwe_keys + (size_t)q * N, N, lwe_keys + (size_t)q * n, n, p->ks_t, p->ks_basebit, sigma_ks, ksk + (size_t)q * per_party);
+    }
+}

@@ -110,6 +110,20 @@ void oracle_mk_lwe_encrypt(const int32_t *keys /*[P][n]*/, int32_t n, int32_t P,
                            uint64_t seed, uint64_t idx, int32_t *rec);
 int32_t oracle_mk_lwe_phase(const int32_t *keys, int32_t n, int32_t P, const int32_t *rec);
 
+/* ---- CCS multi-key scheme: mk_bootstrap / mk_gate_nand (J/mk_internals.jl:477-536,714-728,805-858; J/mk_gates.jl:7-13) ----
+ * bk int32[P][n][3][l][N] = d1, f0, f1 of every MKTGswUESample; pk int32[P][l][N]; crs int32[l][N]; ksk int32[P][N][t][base-1][n+1];
+ * accumulator int32[P+1][N] = (a_0 .. a_{P-1}, b); extracted sample int32[P*N+1] */
+typedef struct oracle_ccs_ctx oracle_ccs_ctx;
+oracle_ccs_ctx *oracle_ccs_ctx_create(const oracle_params *p, const int32_t *bk, const int32_t *pk, const int32_t *crs, const int32_t *ksk);
+void oracle_ccs_ctx_destroy(oracle_ccs_ctx *c);
+void oracle_ccs_uniproduct(const oracle_ccs_ctx *c, int32_t party, int32_t j, const int32_t *acc, int32_t *out, int use_schoolbook);
+void oracle_ccs_mux_rotate(const oracle_ccs_ctx *c, int32_t party, int32_t j, int32_t barai, int32_t *acc, int use_schoolbook);
+void oracle_ccs_bootstrap_wo_keyswitch(const oracle_ccs_ctx *c, int32_t mu, const int32_t *x, int32_t *out, int use_schoolbook);
+void oracle_ccs_keyswitch(const oracle_ccs_ctx *c, const int32_t *in, int32_t *out);
+int oracle_ccs_gates(const oracle_ccs_ctx *c, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count, int use_schoolbook);
+void oracle_keygen_ccs(const oracle_params *p, uint64_t seed, double sigma_bk, double sigma_ks, int32_t *lwe_keys, int32_t *rlwe_keys,
+                       int32_t *bk, int32_t *pk, int32_t *crs, int32_t *ksk);
+
 /* ---- LWE -> TLWE conversion, threshold partial / final decryption (k = 1)   src/libthfhe.cpp:270-348 ---- */
 void oracle_tlwe_from_lwe(const int32_t *lwe /*[N+1]*/, int32_t N, int32_t *tlwe_a /*[N]*/, int32_t *tlwe_b /*[N]*/);
 void oracle_partial_decrypt(const int32_t *key_share, const int32_t *tlwe_a, const int32_t *noise, int32_t N, int32_t *partial);

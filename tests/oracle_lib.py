@@ -42,6 +42,9 @@ PARAM_SETS = {
     "MK3": dict(n=510, N=1024, k=1, l=2, Bgbit=7, ks_t=5, ks_basebit=2, torus_bits=64, parties=3),
     "MK4": dict(n=510, N=1024, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
     "MK4-N2048": dict(n=510, N=2048, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
+    # CCS scheme (mk_bootstrap / mk_gate_nand): mktfhe_parameters_2party / _4party, J/mk_api.jl:4-10,56-62
+    "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
+    "CCS4": dict(n=560, N=1024, k=1, l=4, Bgbit=8, ks_t=8, ks_basebit=2, torus_bits=32, parties=4),
 }
 # noise standard deviations (torus units): J/api.jl:101-115 (SK-128: 2^-15 / 2^-25 per src/libthfhe.cpp:325-326),
 # J/mk_api.jl:32-38 (MK2), :84-90 (MK4)
@@ -53,6 +56,8 @@ SIGMAS = {
     "MK3": dict(lwe=2.0 ** -13.26, bk=2.0 ** -30.70, ks=2.0 ** -13.26),
     "MK4": dict(lwe=2.0 ** -13.26, bk=2.0 ** -30.70, ks=2.0 ** -13.26),
     "MK4-N2048": dict(lwe=2.0 ** -13.26, bk=2.0 ** -30.70, ks=2.0 ** -13.26),
+    "CCS2": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
+    "CCS4": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
 }
 
 
@@ -107,6 +112,14 @@ def lib():
         "oracle_keygen_mk": (None, [PP, C.c_uint64, C.c_double, C.c_double, i32p, i64p, i64p, i32p]),
         "oracle_lwe_encrypt": (None, [i32p, C.c_int32, C.c_int32, C.c_double, C.c_uint64, C.c_uint64, i32p]),
         "oracle_lwe_phase": (C.c_int32, [i32p, C.c_int32, i32p]),
+        "oracle_ccs_ctx_create": (vp, [PP, i32p, i32p, i32p, i32p]),
+        "oracle_ccs_ctx_destroy": (None, [vp]),
+        "oracle_ccs_uniproduct": (None, [vp, C.c_int32, C.c_int32, i32p, i32p, C.c_int]),
+        "oracle_ccs_mux_rotate": (None, [vp, C.c_int32, C.c_int32, C.c_int32, i32p, C.c_int]),
+        "oracle_ccs_bootstrap_wo_keyswitch": (None, [vp, C.c_int32, i32p, i32p, C.c_int]),
+        "oracle_ccs_keyswitch": (None, [vp, i32p, i32p]),
+        "oracle_ccs_gates": (C.c_int, [vp, C.c_int, i32p, i32p, i32p, C.c_size_t, C.c_int]),
+        "oracle_keygen_ccs": (None, [PP, C.c_uint64, C.c_double, C.c_double, i32p, i32p, i32p, i32p, i32p, i32p]),
         "oracle_tlwe_from_lwe": (None, [i32p, C.c_int32, i32p, i32p]),
         "oracle_partial_decrypt": (None, [i32p, i32p, i32p, C.c_int32, i32p]),
         "oracle_final_decrypt": (C.c_int32, [i32p, i32p, C.c_int32, C.c_int32, i32p]),
@@ -196,6 +209,64 @@ class MKKeys:
 
     def decrypt_bits(self, recs):
         return self.phases(recs) > 0
+
+
+def ccs_bk_shape(p):
+    return (p.parties, p.n, 3, p.l, p.N)
+
+
+class CCSKeys:
+    """Key material of the CCS multi-key scheme (SecretKey / SharedKey / CloudKeyPart of J/mk_api.jl:368-384)."""
+
+    def __init__(self, params, seed, sigma_bk, sigma_ks):
+        p = self.params = params
+        self.lwe_keys = np.zeros((p.parties, p.n), np.int32)
+        self.rlwe_keys = np.zeros((p.parties, p.N), np.int32)
+        self.bk = np.zeros(ccs_bk_shape(p), np.int32)
+        self.pk = np.zeros((p.parties, p.l, p.N), np.int32)
+        self.crs = np.zeros((p.l, p.N), np.int32)
+        self.ksk = np.zeros(mk_ksk_shape(p), np.int32)
+        lib().oracle_keygen_ccs(C.byref(p), seed, sigma_bk, sigma_ks, p32(self.lwe_keys), p32(self.rlwe_keys), p32(self.bk), p32(self.pk),
+                                p32(self.crs), p32(self.ksk))
+
+    encrypt_bits = MKKeys.encrypt_bits
+    phases = MKKeys.phases
+    decrypt_bits = MKKeys.decrypt_bits
+
+
+class CCSOracle:
+    def __init__(self, params, K):
+        self.params, self.K = params, K
+        self.h = lib().oracle_ccs_ctx_create(C.byref(params), p32(K.bk), p32(K.pk), p32(K.crs), p32(K.ksk))
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_ccs_ctx_destroy(self.h)
+            self.h = None
+
+    def gates(self, op, in0, in1, schoolbook=False):
+        in0, in1 = np.ascontiguousarray(in0, np.int32), np.ascontiguousarray(in1, np.int32)
+        out = np.zeros_like(in0)
+        assert lib().oracle_ccs_gates(self.h, op, p32(in0), p32(in1), p32(out), in0.shape[0], int(schoolbook)) == 0
+        return out
+
+    def bootstrap_wo_keyswitch(self, x, mu=1 << 29, schoolbook=False):
+        x = np.ascontiguousarray(x, np.int32)
+        out = np.zeros(self.params.N * self.params.parties + 1, np.int32)
+        lib().oracle_ccs_bootstrap_wo_keyswitch(self.h, mu, p32(x), p32(out), int(schoolbook))
+        return out
+
+    def keyswitch(self, u):
+        u = np.ascontiguousarray(u, np.int32)
+        out = np.zeros(self.params.n * self.params.parties + 1, np.int32)
+        lib().oracle_ccs_keyswitch(self.h, p32(u), p32(out))
+        return out
+
+    def mux_rotate(self, party, j, barai, acc, schoolbook=False):
+        acc = np.ascontiguousarray(acc, np.int32).copy()
+        lib().oracle_ccs_mux_rotate(self.h, party, j, barai, p32(acc), int(schoolbook))
+        return acc
 
 
 class Oracle:
