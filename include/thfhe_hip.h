@@ -161,6 +161,21 @@ int thfhe_mk_sync(thfhe_mk_ctx *ctx);
 int thfhe_mk_set_profiling(thfhe_mk_ctx *ctx, int enabled);
 int thfhe_mk_last_timings(thfhe_mk_ctx *ctx, float ms[4]);
 
+/* ---- CCS multi-key scheme: the reference's `mk_bootstrap` / `mk_gate_nand` ---------------------------------
+ *   thfhe_ccs_gates      <- mk_gate_nand(ck, x, y)            J/mk_gates.jl:7-13 (AND / OR / XOR share the bootstrap with their own linear part)
+ *   thfhe_ccs_bootstrap  <- mk_bootstrap(bk, ks, mu, x)       J/mk_internals.jl:855-858 (UniProduct_old :477-536, mk_keyswitch :714-728)
+ *   thfhe_ccs_ctx_create <- MKBootstrapKey(parts, shared_key) J/mk_internals.jl:778-802 (forward_transform of every key polynomial)
+ * Torus32, N = 1024, k = 1.  HOST tables, coefficient domain:
+ *   bk  int32[P][n][3][l][N]   d1, f0, f1 of every MKTGswUESample (J/mk_internals.jl:338-448)
+ *   pk  int32[P][l][N]         PublicKey.b;    crs int32[l][N]  SharedKey.a;    ksk int32[P][N][t][base-1][n+1]
+ * Records: int32[P*n+1] = a[p*n + i], b (MKLweSample). */
+typedef struct thfhe_ccs_ctx thfhe_ccs_ctx;
+int thfhe_ccs_ctx_create(const thfhe_params *params, const int32_t *bk, const int32_t *pk, const int32_t *crs, const int32_t *ksk, int device,
+                         thfhe_ccs_ctx **out);
+void thfhe_ccs_ctx_destroy(thfhe_ccs_ctx *ctx);
+int thfhe_ccs_gates(thfhe_ccs_ctx *ctx, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count);
+int thfhe_ccs_bootstrap(thfhe_ccs_ctx *ctx, int32_t mu, const int32_t *x, int32_t *out, size_t count);
+
 /* ---- LWE -> TLWE conversion and threshold partial / final decryption: the step after the gate path in the reference's C++
  * applications.  k = 1, N = 1024; all pointers are HOST arrays.
  *   thfhe_tlwe_from_lwe     <- TLweFromLwe(ring_cipher, cipher, tlwe_params)       src/libthfhe.cpp:340-348, src/KNN_medical_data.cpp:492-500

@@ -44,6 +44,9 @@ PARAM_SETS = {
     "MK4": dict(n=510, N=1024, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
     # BASELINE.json configs[4] wording ("4-party 3-gen MK-TFHE, N=2048 l=3"): the reference's 4-party set on the larger ring
     "MK4-N2048": dict(n=510, N=2048, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
+    # CCS scheme (mk_bootstrap / mk_gate_nand): mktfhe_parameters_2party / _4party, mk_api.jl:4-10,56-62
+    "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
+    "CCS4": dict(n=560, N=1024, k=1, l=4, Bgbit=8, ks_t=8, ks_basebit=2, torus_bits=32, parties=4),
 }
 
 
@@ -82,6 +85,10 @@ SIGNATURES = {
     "thfhe_set_coop_threshold": (C.c_int, [_vp, C.c_int]),
     "thfhe_set_profiling": (C.c_int, [_vp, C.c_int]),
     "thfhe_last_timings": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "thfhe_ccs_ctx_create": (C.c_int, [C.POINTER(Params), _i32p, _i32p, _i32p, _i32p, C.c_int, C.POINTER(_vp)]),
+    "thfhe_ccs_ctx_destroy": (None, [_vp]),
+    "thfhe_ccs_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, C.c_size_t]),
+    "thfhe_ccs_bootstrap": (C.c_int, [_vp, C.c_int32, _i32p, _i32p, C.c_size_t]),
     "thfhe_poly_ctx_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
     "thfhe_poly_ctx_destroy": (None, [_vp]),
     "thfhe_tlwe_from_lwe": (C.c_int, [_vp, _i32p, _i32p, _i32p, C.c_size_t]),
@@ -402,6 +409,49 @@ class MKCloudKey:
         ms = (C.c_float * 4)()
         _check(lib().thfhe_mk_last_timings(self.h, ms))
         return dict(prologue_ms=ms[0], blind_rotate_ms=ms[1], keyswitch_ms=ms[2], total_ms=ms[3])
+
+
+class CCSCloudKey:
+    """MKCloudKey of the CCS scheme (mk_api.jl:392-408): MKBootstrapKey (uni-encrypted key bits, public keys, shared key) and the
+    parties' KeyswitchKeys on one MI355X.  bk int32[P][n][3][l][N] (d1, f0, f1), pk int32[P][l][N], crs int32[l][N], ksk as MKCloudKey."""
+
+    def __init__(self, params, bk, pk, crs, ksk, device=0):
+        self.params = p = params
+        arrs = [np.ascontiguousarray(a, np.int32) for a in (bk, pk, crs, ksk)]
+        sizes = (p.parties * p.n * 3 * p.l * p.N, p.parties * p.l * p.N, p.l * p.N, p.parties * p.N * p.ks_t * ((1 << p.ks_basebit) - 1) * (p.n + 1))
+        if any(a.size != s for a, s in zip(arrs, sizes)):
+            raise ValueError("key table has the wrong size for these parameters")
+        h = _vp()
+        _check(lib().thfhe_ccs_ctx_create(C.byref(p), *[_p32(a) for a in arrs], device, C.byref(h)))
+        self.h = h
+        self.words = p.parties * p.n + 1
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.thfhe_ccs_ctx_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gates(self, op, x, y):
+        x, y = _rec(x, self.words), _rec(y, self.words)
+        out = np.empty_like(x)
+        _check(lib().thfhe_ccs_gates(self.h, op, _p32(x), _p32(y), _p32(out), x.shape[0]))
+        return out
+
+    def bootstrap(self, x, mu=MU8):
+        x = _rec(x, self.words)
+        out = np.empty_like(x)
+        _check(lib().thfhe_ccs_bootstrap(self.h, mu, _p32(x), _p32(out), x.shape[0]))
+        return out
+
+
+def mk_gate_nand(ck, x, y): return ck.gates(NAND, x, y)          # mk_gates.jl:7-13 (CCS scheme)
+def mk_bootstrap(ck, mu, x): return ck.bootstrap(x, mu)         # mk_internals.jl:855-858
 
 
 # the reference's 3-gen gate API (3gen_mk_gates.jl:8-150); `bk` is the MKCloudKey (it holds bk and ks together)
