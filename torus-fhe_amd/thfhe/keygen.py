@@ -196,6 +196,45 @@ class MKSecretKeySet:
         return self.phase(recs) > 0
 
 
+class CCSSecretKeySet:
+    """CCS multi-key material (SecretKey / SharedKey / CloudKeyPart, mk_api.jl:368-384): per party a binary LWE key, a binary RLWE
+    key, PublicKey b_i = s (*) a_i + e (mk_internals.jl:209-245), the uni-encryption (d1, f0, f1) of every key bit
+    (mk_tgsw_encrypt, :390-448; c0, c1, d0 are not read by UniProduct_old) and a KeyswitchKey."""
+
+    def __init__(self, params, seed=0x5EED0001, sigma_lwe=3.05e-5, sigma_bk=3.72e-9, sigma_ks=3.05e-5):
+        p = self.params = params
+        assert p.k == 1 and p.torus_bits == 32
+        rng = np.random.default_rng(seed)
+        P, n, N, l = p.parties, p.n, p.N, p.l
+        self.sigma_lwe = sigma_lwe
+        self.lwe_keys = rng.integers(0, 2, (P, n)).astype(np.int32)
+        self.rlwe_keys = rng.integers(0, 2, (P, N)).astype(np.int32)
+        self.crs = rng.integers(-2**31, 2**31, size=(l, N), dtype=np.int64).astype(np.int32)                 # SharedKey.a
+        gauss = lambda shape: dtot32(rng.standard_normal(shape) * sigma_bk).astype(np.int64)
+        self.pk = np.stack([(polymul_small32(self.crs, self.rlwe_keys[q]).astype(np.int64) + gauss((l, N))) for q in range(P)])
+        self.pk = self.pk.astype(np.uint32).view(np.int32)
+        g = np.array([1 << (32 - (i + 1) * p.Bgbit) for i in range(l)], np.int64)
+        bk = np.empty((P, n, 3, l, N), np.int64)
+        for q in range(P):
+            r = rng.integers(0, 2, (n, N)).astype(np.int64)                                                   # the shared randomness r, one per key bit
+            f1 = rng.integers(-2**31, 2**31, size=(n, l, N), dtype=np.int64).astype(np.int32)
+            for i in range(l):
+                # d1_i = e + r (*) a_i + m g_i ; r (*) a_i = rows of r times the fixed polynomial a_i
+                ra = (r.astype(np.float64) @ negacyclic_matrix((self.crs[i].astype(np.int64) & 0xFFFF).astype(np.float64))).astype(np.int64) \
+                    + ((r.astype(np.float64) @ negacyclic_matrix((self.crs[i].astype(np.int64) >> 16).astype(np.float64))).astype(np.int64) << 16)
+                d1 = ra + gauss((n, N))
+                d1[:, 0] += self.lwe_keys[q].astype(np.int64) * g[i]
+                bk[q, :, 0, i, :] = d1
+                bk[q, :, 1, i, :] = polymul_small32(f1[:, i, :], self.rlwe_keys[q]).astype(np.int64) + gauss((n, N)) + r * g[i]   # f0_i = e + s (*) f1_i + r g_i
+                bk[q, :, 2, i, :] = f1[:, i, :]
+        self.bk = bk.astype(np.uint32).view(np.int32)
+        self.ksk = np.stack([gen_keyswitch_key(rng, self.rlwe_keys[q], self.lwe_keys[q], p.ks_t, p.ks_basebit, sigma_ks) for q in range(P)])
+
+    encrypt = MKSecretKeySet.encrypt
+    phase = MKSecretKeySet.phase
+    decrypt = MKSecretKeySet.decrypt
+
+
 def negacyclic_matrix_u64(b):
     """Three float64 limb matrices of the torus polynomial b: small (*) b = sum_limb (small @ M_limb) << shift."""
     b = np.asarray(b).view(np.uint64)
