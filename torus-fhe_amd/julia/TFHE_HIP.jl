@@ -10,7 +10,8 @@ module TFHE_HIP
 export HipCloudKey, HipMKCloudKey, gate_nand, gate_or, gate_and, gate_xor, gate_xnor, gate_nor, gate_andny, gate_andyn,
        gate_orny, gate_oryn, gate_mux, gate_not, bootstrap, bootstrap_wo_keyswitch, keyswitch,
        mk_gate_nand_3gen, mk_gate_or_3gen, mk_gate_and_3gen, mk_gate_xor_3gen, mk_gate_3and_3gen, mk_gate_mux_3gen,
-       mk_gate_not_3gen, mk_bootstrap_3gen
+       mk_gate_not_3gen, mk_bootstrap_3gen, HipCCSCloudKey, mk_gate_nand, mk_bootstrap, dag_run,
+       HipPolyContext, TLweFromLwe, PartialDecrypt, finalDecrypt
 
 const LIB = get(ENV, "THFHE_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libthfhe_hip.so"))
 
@@ -126,6 +127,85 @@ function mk_bootstrap_3gen(ck::HipMKCloudKey, mu::Int64, x::Matrix{Int32})      
     out = similar(x)
     check(ccall((:thfhe_mk_bootstrap, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Csize_t), ck.h, mu, x, out, size(x, 2)))
     out
+end
+
+# ---- CCS multi-key scheme: mk_gate_nand / mk_bootstrap (mk_gates.jl:7-13, mk_internals.jl:855-858) ---------------------
+mutable struct HipCCSCloudKey
+    h::Ptr{Cvoid}
+    params::Params
+end
+
+"""
+    HipCCSCloudKey(params, bk, pk, crs, ksk; device=0)
+
+C-order tables: `bk` Int32[P][n][3][l][N] = (d1, f0, f1) of every `MKTGswUESample` of `BootstrapKeyPart.key_uni_enc`;
+`pk` Int32[P][l][N] = `PublicKey.b`; `crs` Int32[l][N] = `SharedKey.a`; `ksk` Int32[P][N][t][base-1][n+1].
+"""
+function HipCCSCloudKey(p::Params, bk::Array{Int32}, pk::Array{Int32}, crs::Array{Int32}, ksk::Array{Int32}; device::Integer=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:thfhe_ccs_ctx_create, LIB), Cint, (Ref{Params}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
+                p, bk, pk, crs, ksk, device, h))
+    ck = HipCCSCloudKey(h[], p)
+    finalizer(c -> ccall((:thfhe_ccs_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.h), ck)
+    ck
+end
+
+function mk_gate_nand(ck::HipCCSCloudKey, x::Matrix{Int32}, y::Matrix{Int32})
+    out = similar(x)
+    check(ccall((:thfhe_ccs_gates, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Csize_t), ck.h, NAND, x, y, out, size(x, 2)))
+    out
+end
+
+function mk_bootstrap(ck::HipCCSCloudKey, mu::Int32, x::Matrix{Int32})
+    out = similar(x)
+    check(ccall((:thfhe_ccs_bootstrap, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}, Csize_t), ck.h, mu, x, out, size(x, 2)))
+    out
+end
+
+# ---- gate DAGs: native ASAP scheduler + device-resident executor (thfhe_dag_run) ----------------------------------------
+"""
+    dag_run(ck, inputs, gates) -> wires
+
+`inputs :: Matrix{Int32}` (n+1, n_inputs); `gates :: Matrix{Int32}` (4, n_gates) = (opcode, in0, in1, in2) per column, 0-based wire
+ids, topological order.  Returns the whole wire table (n+1, n_inputs + n_gates).
+"""
+function dag_run(ck::HipCloudKey, inputs::Matrix{Int32}, gates::Matrix{Int32})
+    ni, ng = size(inputs, 2), size(gates, 2)
+    wires = zeros(Int32, size(inputs, 1), ni + ng)
+    wires[:, 1:ni] .= inputs
+    check(ccall((:thfhe_dag_run, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Csize_t, Ptr{Int32}, Csize_t, Ptr{Int64}), ck.h, wires, ni, gates, ng, C_NULL))
+    wires
+end
+
+# ---- after the gate path: TLweFromLwe / PartialDecrypt / finalDecrypt (src/libthfhe.cpp:270-348) ---------------------------
+mutable struct HipPolyContext
+    h::Ptr{Cvoid}
+end
+function HipPolyContext(; device::Integer=0, N::Integer=1024)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:thfhe_poly_ctx_create, LIB), Cint, (Cint, Cint, Ref{Ptr{Cvoid}}), device, N, h))
+    c = HipPolyContext(h[])
+    finalizer(x -> ccall((:thfhe_poly_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), c)
+    c
+end
+function TLweFromLwe(c::HipPolyContext, lwe::Matrix{Int32})                      # (N+1, count) -> a, b of size (N, count)
+    cnt = size(lwe, 2); N = size(lwe, 1) - 1
+    a, b = zeros(Int32, N, cnt), zeros(Int32, N, cnt)
+    check(ccall((:thfhe_tlwe_from_lwe, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Csize_t), c.h, lwe, a, b, cnt))
+    a, b
+end
+function PartialDecrypt(c::HipPolyContext, key_share::Vector{Int32}, a::Matrix{Int32}, noise::Union{Nothing, Matrix{Int32}}=nothing)
+    out = similar(a)
+    np = noise === nothing ? Ptr{Int32}(C_NULL) : pointer(noise)
+    GC.@preserve noise check(ccall((:thfhe_partial_decrypt, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Csize_t),
+                                   c.h, key_share, a, np, out, size(a, 2)))
+    out
+end
+function finalDecrypt(c::HipPolyContext, b::Matrix{Int32}, partials::Array{Int32, 3})      # partials (N, count, t)
+    bits = zeros(Int32, size(b, 2))
+    check(ccall((:thfhe_final_decrypt, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Cint, Ptr{Int32}, Ptr{Int32}, Csize_t),
+                c.h, b, partials, size(partials, 3), C_NULL, bits, size(b, 2)))
+    bits .> 0
 end
 
 end # module
