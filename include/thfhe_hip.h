@@ -130,6 +130,9 @@ int thfhe_mk_gates_mixed(thfhe_mk_ctx *ctx, const int32_t *ops, const int32_t *i
 /* Batches of at most `max_single_jobs` rotations run one gate per workgroup (latency), larger ones two gates per workgroup sharing
  * every key chunk (throughput; N = 1024, l <= 3).  Default 256 = one workgroup per CU of an MI355X. */
 int thfhe_mk_set_pair_threshold(thfhe_mk_ctx *ctx, long max_single_jobs);
+/* Gate-DAG evaluation for the 3-gen scheme (same contract as thfhe_dag_run; records of P*n+1 words): the reference's multi-key integer
+ * circuits mk_add_3gen ... mk_int_mul_3gen (J/3gen_mk_gates.jl:183-362).  Opcodes: NAND / OR / AND / XOR, AND3, MUX, NOT, COPY. */
+int thfhe_mk_dag_run(thfhe_mk_ctx *ctx, int32_t *wires, size_t n_inputs, const int32_t *gates, size_t n_gates, int64_t *stats);
 int thfhe_mk_bootstrap(thfhe_mk_ctx *ctx, int64_t mu, const int32_t *x, int32_t *out, size_t count);
 /* Party-sharded building blocks (optional mode: one rank per party holds only that party's keys, i.e. a
  * context created with parties = 1 from party p's key part).  All pointers are DEVICE pointers; calls enqueue on the context's

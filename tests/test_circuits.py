@@ -216,3 +216,78 @@ def test_reduced_knn_decision_on_gpu():
         assert np.array_equal(K.decrypt(v), Cc.simulate_ext(c2, bits))
         assert np.array_equal(v, Cc.evaluate_levels(ck, c2, K.encrypt(np.array(bits), seed=9)))
     ck.close()
+
+
+def test_mk_comparison_and_multiplier_circuits_plaintext():
+    # J/3gen_mk_gates.jl:258-362 (bit vectors LSB-first, two's complement comparisons)
+    from thfhe import circuits as Cc
+    W = 6
+    cir = Cc.Circuit()
+    a, b = cir.inputs(W), cir.inputs(W)
+    one, zero = cir.inputs(1)[0], cir.inputs(1)[0]
+    grt, leq, geq = Cc.mk_grt_3gen(cir, a, b, one), Cc.mk_leq_3gen(cir, a, b, one), Cc.mk_geq_3gen(cir, a, b, one)
+    add = Cc.mk_int_add_with_carry_3gen(cir, a, b, zero)
+    mul = Cc.mk_int_mul_3gen(cir, a, b, zero)
+    lsb = lambda v, w: [(v >> i) & 1 for i in range(w)]
+    val = lambda bits: sum(int(x) << i for i, x in enumerate(bits))
+
+    def ref_mul(x, y):   # the reference's dataflow on plain integers (1-based rows; the last addition re-uses row ctr)
+        rows = [x if (y >> i) & 1 else 0 for i in range(W)]
+        result = [0] * (2 * W + 1)
+        result[0] = rows[0] & 1
+        tmp = rows[0] >> 1
+        ctr = 1
+        for i in range(2, W):
+            t = tmp + rows[i - 1]
+            result[i - 1] = t & 1
+            tmp = t >> 1
+            ctr = i
+        t = tmp + rows[ctr - 1]
+        for i in range(W + 1):
+            result[i + ctr] = (t >> i) & 1
+        return val(result[:W])
+
+    rng = np.random.default_rng(4)
+    for _ in range(40):
+        x, y = (int(v) for v in rng.integers(0, 1 << (W - 1), 2))       # non-negative, so the sign bit of x - y is the comparison
+        v = Cc.simulate(cir, lsb(x, W) + lsb(y, W) + [1, 0])
+        assert bool(v[grt]) == (x > y) and bool(v[leq]) == (x <= y) and bool(v[geq]) == (x >= y)
+        assert val(v[add]) == x + y
+        assert val(v[mul]) == ref_mul(x, y)
+    assert ref_mul(3, 1) == 3 and ref_mul(5, 2) == 10                   # agrees with true multiplication when the re-used row is zero
+
+
+@pytest.mark.gpu
+def test_mk_dag_executor_on_gpu(O):
+    # thfhe_mk_dag_run: comparison and multiplier circuits of J/3gen_mk_gates.jl:258-362 plus AND3 / MUX / NOT, natively scheduled;
+    # every wire must decrypt to the plaintext simulation and equal the host-driven level loop bit for bit
+    import thfhe
+    from thfhe import circuits as Cc
+    p = O.make_params("MK2", n=96)      # reduced LWE dimension keeps the noise budget of these depths comfortable
+    sg = O.SIGMAS["MK2"]
+    K = O.MKKeys(p, 0x5EED0001, sg["bk"], sg["ks"])
+    ck = thfhe.MKCloudKey(thfhe.make_params(**p.as_dict()), K.bk, K.ksk, device=0)
+    W = 4
+    cir = Cc.Circuit()
+    a, b = cir.inputs(W), cir.inputs(W)
+    one, zero = cir.inputs(1)[0], cir.inputs(1)[0]
+    outs = dict(grt=Cc.mk_grt_3gen(cir, a, b, one), geq=Cc.mk_geq_3gen(cir, a, b, one))
+    mul = Cc.mk_int_mul_3gen(cir, a, b, zero)
+    extra = cir.gate(thfhe.MUX, cir.gate(thfhe.NOT, a[0]), cir.gate(thfhe.AND3, a[1], b[1], one), b[0])
+    for x, y in ((5, 3), (2, 7), (6, 6)):
+        bits = [(x >> i) & 1 for i in range(W)] + [(y >> i) & 1 for i in range(W)] + [1, 0]
+        enc = K.encrypt_bits(bits, sg["lwe"], 70 + x)
+        stats = {}
+        vals = Cc.evaluate(ck, cir, enc, stats)
+        sim = Cc.simulate_mk(cir, bits)
+        assert np.array_equal(K.decrypt_bits(vals), sim)
+        assert bool(K.decrypt_bits(vals[[outs["grt"]]])[0]) == (x > y) and bool(K.decrypt_bits(vals[[outs["geq"]]])[0]) == (x >= y)
+        assert stats["launches"] < stats["gates"] / 2
+    # two-input-only circuit: the native executor equals the host-driven loop (thfhe_mk_gates_mixed per level) bit for bit
+    c2 = Cc.Circuit()
+    a2, b2 = c2.inputs(W), c2.inputs(W)
+    z2 = c2.inputs(1)[0]
+    Cc.mk_int_add_with_carry_3gen(c2, a2, b2, z2)
+    enc = K.encrypt_bits([1, 0, 1, 1, 0, 1, 1, 0, 0], sg["lwe"], 99)
+    assert np.array_equal(Cc.evaluate(ck, c2, enc), Cc.evaluate_levels(ck, c2, enc))
+    ck.close()

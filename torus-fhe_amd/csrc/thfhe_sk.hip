@@ -20,6 +20,7 @@
 
 #include "../../include/thfhe_hip.h"
 #include "thfhe_common.h"
+#include "thfhe_dag.h"
 #include "thfhe_lane.h"
 
 using namespace thfhe;
@@ -392,30 +393,6 @@ __global__ __launch_bounds__(256) void sk_linear_kernel(const int32_t *__restric
     if (q < words) out[q] = negate ? (int32_t)(0u - (uint32_t)in0[q]) : in0[q];
 }
 
-// gate-DAG executor plumbing: wires live in one device table [n_wires][words]; a level's operands are gathered into the
-// contiguous staging arrays the bootstrap kernels read, its outputs scattered back
-__global__ __launch_bounds__(256) void sk_gather_kernel(const int32_t *__restrict__ wires, const int32_t *__restrict__ idx, int32_t *__restrict__ dst,
-                                                         long count, int words) {
-    const long g = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (g < count && i < words) dst[g * words + i] = wires[(size_t)idx[g] * words + i];
-}
-__global__ __launch_bounds__(256) void sk_scatter_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int32_t *__restrict__ wires,
-                                                          long count, int words) {
-    const long g = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (g < count && i < words) wires[(size_t)idx[g] * words + i] = src[g * words + i];
-}
-// NOT / COPY gates of one sub-level (no gate of the launch reads another's output)
-__global__ __launch_bounds__(256) void sk_wire_linear_kernel(int32_t *__restrict__ wires, const int32_t *__restrict__ in_idx,
-                                                              const int32_t *__restrict__ out_idx, const int32_t *__restrict__ ops, long count, int words) {
-    const long g = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (g >= count || i >= words) return;
-    const uint32_t v = (uint32_t)wires[(size_t)in_idx[g] * words + i];
-    wires[(size_t)out_idx[g] * words + i] = (int32_t)(ops[g] == THFHE_NOT ? 0u - v : v);
-}
-
 }  // namespace
 
 // ======================================================================================================
@@ -749,106 +726,48 @@ int thfhe_gates_mixed(thfhe_ctx *c, const int32_t *ops, const int32_t *in0, cons
     return THFHE_OK;
 }
 
-// Gate-DAG evaluation: ASAP levelising scheduler + device-resident executor.  The reference's applications issue
-// these gates as sequential boots* calls (src/KNN_medical_data.cpp:127-489); here every level is one blind-rotate launch per gate
-// class, the wire table stays in HBM and nothing synchronises with the host between levels.
+// Gate-DAG evaluation: ASAP levelising scheduler (thfhe_dag.h) + device-resident executor.  The reference's
+// applications issue these gates as sequential boots* calls (src/KNN_medical_data.cpp:127-489); here every level is one blind-rotate
+// launch per gate class, the wire table stays in HBM and nothing synchronises with the host between levels.
 int thfhe_dag_run(thfhe_ctx *c, int32_t *wires, size_t n_inputs, const int32_t *gates, size_t n_gates, int64_t *stats) {
     if (!c || !wires || (!gates && n_gates)) return thfhe_fail(THFHE_E_INVALID, "null argument");
-    const size_t n_wires = n_inputs + n_gates;
-    if (n_wires > (size_t)INT32_MAX / 2) return thfhe_fail(THFHE_E_INVALID, "too many wires");
-    // ---- schedule: (depth, sub) per wire; bootstrapped gates add one level, NOT / COPY ride on their operand's level -----------
-    std::vector<int32_t> depth(n_wires, 0), sub(n_wires, 0);
-    int32_t max_depth = 0, max_sub = 0;
-    for (size_t g = 0; g < n_gates; g++) {
-        const int32_t op = gates[4 * g], w = (int32_t)(n_inputs + g);
-        const bool lin = op == THFHE_NOT || op == THFHE_COPY;
-        const int nin = lin ? 1 : (op == THFHE_MUX ? 3 : 2);
-        if (!(lin || op == THFHE_MUX || (op >= THFHE_NAND && op <= THFHE_ORYN))) return thfhe_fail(THFHE_E_INVALID, "unknown gate opcode in the DAG");
-        int32_t d = 0, s = 0;
-        for (int q = 0; q < nin; q++) {
-            const int32_t in = gates[4 * g + 1 + q];
-            if (in < 0 || in >= w) return thfhe_fail(THFHE_E_INVALID, "gate operand is not an earlier wire (gates must be in topological order)");
-            if (depth[in] > d || (depth[in] == d && sub[in] > s)) d = depth[in], s = sub[in];
-        }
-        if (lin) s += 1; else d += 1, s = 0;
-        depth[w] = d, sub[w] = s;
-        if (d > max_depth) max_depth = d;
-        if (s > max_sub) max_sub = s;
-    }
-    // bucket the gates: slot (d, s, class) with class 0 = two-input, 1 = MUX (s = 0 only), 2 = NOT / COPY (s >= 1)
-    struct Batch { int32_t d, s, cls; std::vector<int32_t> g; };
-    std::vector<Batch> batches;
-    {
-        std::vector<std::vector<int32_t>> two(max_depth + 1), mux(max_depth + 1);
-        std::vector<std::vector<std::vector<int32_t>>> lin(max_depth + 1);
-        for (size_t g = 0; g < n_gates; g++) {
-            const int32_t op = gates[4 * g], w = (int32_t)(n_inputs + g);
-            if (op == THFHE_NOT || op == THFHE_COPY) {
-                auto &L = lin[depth[w]];
-                if ((int)L.size() < sub[w]) L.resize(sub[w]);
-                L[sub[w] - 1].push_back((int32_t)g);
-            } else {
-                (op == THFHE_MUX ? mux : two)[depth[w]].push_back((int32_t)g);
-            }
-        }
-        for (int32_t d = 0; d <= max_depth; d++) {
-            if (!two[d].empty()) batches.push_back(Batch{d, 0, 0, std::move(two[d])});
-            if (!mux[d].empty()) batches.push_back(Batch{d, 0, 1, std::move(mux[d])});
-            for (size_t q = 0; q < lin[d].size(); q++)
-                if (!lin[d][q].empty()) batches.push_back(Batch{d, (int32_t)q + 1, 2, std::move(lin[d][q])});
-        }
-    }
-    // ---- index tables: per batch [ops | in0 | in1 | in2 | out], uploaded once ---------------------------------------------------
-    std::vector<int32_t> tab;
-    tab.reserve(5 * n_gates);
-    std::vector<size_t> off(batches.size());
-    size_t max_width = 0, max_rot = 0;
-    int64_t rotations = 0;
-    for (size_t b = 0; b < batches.size(); b++) {
-        const auto &G = batches[b].g;
-        off[b] = tab.size();
-        for (int col = 0; col < 5; col++)
-            for (int32_t g : G) tab.push_back(col == 4 ? (int32_t)(n_inputs + g) : (col == 0 ? gates[4 * g] : (gates[4 * g + col] < 0 ? 0 : gates[4 * g + col])));
-        if (G.size() > max_width) max_width = G.size();
-        const size_t rot = batches[b].cls == 0 ? G.size() : (batches[b].cls == 1 ? 2 * G.size() : 0);
-        if (rot > max_rot) max_rot = rot;
-        rotations += (int64_t)rot;
-    }
-    if (stats) {
-        stats[0] = max_depth, stats[1] = 0, stats[2] = rotations, stats[3] = (int64_t)max_width;
-        for (const auto &b : batches) stats[1] += b.cls != 2;
-    }
+    DagPlan plan;
+    int rc = dag_plan(gates, n_inputs, n_gates, [](int op) { return op == THFHE_NOT || op == THFHE_COPY ? 2 : (op == THFHE_MUX ? 1 : (op >= THFHE_NAND && op <= THFHE_ORYN ? 0 : -1)); },
+                      plan);
+    if (rc) return rc;
+    if (stats) plan.fill_stats(stats);
     if (n_gates == 0) return THFHE_OK;
+    const size_t n_wires = n_inputs + n_gates;
     std::lock_guard<std::mutex> lk(c->mu);
     THFHE_HIP(hipSetDevice(c->device));
     const int words = c->p.n + 1;
-    int rc = ensure_workspace(c, max_rot ? max_rot : 1);
-    if (!rc) rc = ensure_stage(c, max_width * words);
+    rc = ensure_workspace(c, plan.max_rot ? plan.max_rot : 1);
+    if (!rc) rc = ensure_stage(c, plan.max_width * words);
     if (rc) return rc;
     int32_t *d_wires = nullptr, *d_tab = nullptr;
     const size_t wbytes = n_wires * (size_t)words * sizeof(int32_t);
     hipError_t e = hipMalloc(&d_wires, wbytes);
-    if (e == hipSuccess) e = hipMalloc(&d_tab, tab.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_tab, plan.tab.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(d_wires, wires, n_inputs * (size_t)words * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, plan.tab.data(), plan.tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
     rc = e == hipSuccess ? THFHE_OK : thfhe_fail_hip(e, "thfhe_dag_run setup");
     const unsigned wb = (unsigned)((words + 255) / 256);
-    for (size_t b = 0; b < batches.size() && rc == THFHE_OK; b++) {
-        const long cnt = (long)batches[b].g.size();
-        const int32_t *t_ops = d_tab + off[b], *t0 = t_ops + cnt, *t1 = t0 + cnt, *t2 = t1 + cnt, *t_out = t2 + cnt;
+    for (size_t b = 0; b < plan.batches.size() && rc == THFHE_OK; b++) {
+        const long cnt = (long)plan.batches[b].count;
+        const int32_t *t_ops = d_tab + plan.batches[b].off, *t0 = t_ops + cnt, *t1 = t0 + cnt, *t2 = t1 + cnt, *t_out = t2 + cnt;
         const dim3 grid(wb, (unsigned)cnt), block(256);
-        if (batches[b].cls == 2) {
-            hipLaunchKernelGGL(sk_wire_linear_kernel, grid, block, 0, c->stream, d_wires, t0, t_out, t_ops, cnt, words);
+        if (plan.batches[b].cls == 2) {
+            hipLaunchKernelGGL(dag_wire_linear_kernel, grid, block, 0, c->stream, d_wires, t0, t_out, t_ops, cnt, words);
             continue;
         }
-        const bool is_mux = batches[b].cls == 1;
-        hipLaunchKernelGGL(sk_gather_kernel, grid, block, 0, c->stream, d_wires, t0, c->d_in[0], cnt, words);
-        hipLaunchKernelGGL(sk_gather_kernel, grid, block, 0, c->stream, d_wires, t1, c->d_in[1], cnt, words);
-        if (is_mux) hipLaunchKernelGGL(sk_gather_kernel, grid, block, 0, c->stream, d_wires, t2, c->d_in[2], cnt, words);
+        const bool is_mux = plan.batches[b].cls == 1;
+        hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, c->stream, d_wires, t0, c->d_in[0], cnt, words);
+        hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, c->stream, d_wires, t1, c->d_in[1], cnt, words);
+        if (is_mux) hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, c->stream, d_wires, t2, c->d_in[2], cnt, words);
         rc = enqueue_rotations(c, is_mux ? THFHE_MUX : THFHE_NAND, c->d_in[0], c->d_in[1], is_mux ? c->d_in[2] : nullptr, (size_t)cnt, is_mux ? 2 : 1,
                                1 << 29, is_mux ? nullptr : t_ops);
         if (!rc) rc = enqueue_keyswitch(c, c->d_u, c->d_out, (size_t)cnt, is_mux ? 2 : 1, false);
-        if (!rc) hipLaunchKernelGGL(sk_scatter_kernel, grid, block, 0, c->stream, c->d_out, t_out, d_wires, cnt, words);
+        if (!rc) hipLaunchKernelGGL(dag_scatter_kernel, grid, block, 0, c->stream, c->d_out, t_out, d_wires, cnt, words);
     }
     if (rc == THFHE_OK) {
         e = hipGetLastError();

@@ -98,6 +98,7 @@ SIGNATURES = {
     "thfhe_mk_ctx_destroy": (None, [_vp]),
     "thfhe_mk_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_gates_mixed": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
+    "thfhe_mk_dag_run": (C.c_int, [_vp, _i32p, C.c_size_t, _i32p, C.c_size_t, _i64p]),
     "thfhe_mk_bootstrap": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_prologue_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_size_t]),
     "thfhe_mk_set_stream": (C.c_int, [_vp, _vp]),
@@ -367,6 +368,16 @@ class MKCloudKey:
         out = np.empty_like(x)
         _check(lib().thfhe_mk_gates_mixed(self.h, _p32(ops), _p32(x), _p32(y), _p32(out), x.shape[0]))
         return out
+
+    def dag_run(self, input_records, gates):
+        """Native levelising scheduler + device-resident executor for 3-gen circuits (thfhe_mk_dag_run)."""
+        x = _rec(input_records, self.words)
+        g = np.ascontiguousarray(gates, np.int32).reshape(-1, 4)
+        wires = np.zeros((x.shape[0] + g.shape[0], self.words), np.int32)
+        wires[:x.shape[0]] = x
+        st = np.zeros(4, np.int64)
+        _check(lib().thfhe_mk_dag_run(self.h, _p32(wires), x.shape[0], _p32(g), g.shape[0], st.ctypes.data_as(_i64p)))
+        return wires, dict(levels=int(st[0]), launches=int(st[1]), rotations=int(st[2]), widest_level=int(st[3]))
 
     def bootstrap(self, x, mu=MU8_64):
         x = _rec(x, self.words)

@@ -178,6 +178,54 @@ def mk_less_3gen(cir, a, b, one):
     return mk_sub_3gen(cir, a, b, one)[-1]
 
 
+def mk_grt_3gen(cir, a, b, one):
+    """a > b: sign bit of b - a, copied, :258-266."""
+    return cir.gate(COPY, mk_sub_3gen(cir, b, a, one)[-1])
+
+
+def mk_leq_3gen(cir, a, b, one):
+    """:269-277."""
+    return cir.gate(XOR, mk_grt_3gen(cir, a, b, one), one)
+
+
+def mk_geq_3gen(cir, a, b, one):
+    """:280-288."""
+    return cir.gate(XOR, mk_less_3gen(cir, a, b, one), one)
+
+
+def mk_int_add_with_carry_3gen(cir, a, b, cin):
+    """WIDTH sum bits + the carry out, :291-310."""
+    out = []
+    for i in range(len(a)):
+        t1 = cir.gate(XOR, a[i], b[i])
+        t2 = cir.gate(AND, a[i], b[i])
+        out.append(cir.gate(XOR, t1, cin))
+        t3 = cir.gate(AND, t1, cin)
+        cin = cir.gate(OR, t2, t3)
+    return out + [cin]
+
+
+def mk_int_mul_3gen(cir, a, b, zero):
+    """Shift-and-add multiplier, low WIDTH bits, :312-362 -- the reference's dataflow verbatim, including its last addition of
+    partial-product row `ctr` (= WIDTH-1, not WIDTH) and its mk_copy_3gen refreshes."""
+    W = len(a)
+    cp = lambda w: cir.gate(COPY, w)
+    BArr = [[cir.gate(AND, a[j], b[i]) for j in range(W)] for i in range(W)]
+    result = [None] * (2 * W + 1)
+    result[0] = cp(BArr[0][0])
+    tmp_in = [cp(BArr[0][i + 1]) for i in range(W - 1)] + [cp(zero)]
+    ctr = 1
+    for i in range(2, W):                      # Julia i = 2 .. WIDTH-1 (1-based row i)
+        t = mk_int_add_with_carry_3gen(cir, tmp_in, BArr[i - 1], zero)
+        result[i - 1] = cp(t[0])
+        tmp_in = [cp(t[j + 1]) for j in range(W)]
+        ctr = i
+    t = mk_int_add_with_carry_3gen(cir, tmp_in, BArr[ctr - 1], zero)
+    for i in range(W + 1):
+        result[i + ctr] = cp(t[i])
+    return [cp(result[i]) for i in range(W)]
+
+
 def simulate(cir, input_bits):
     """Plaintext evaluation of the DAG (wiring check): bool[n_inputs] -> bool[n_wires]."""
     from . import ANDNY, ANDYN, NAND, NOR, ORNY, ORYN, XNOR
@@ -200,6 +248,23 @@ def simulate(cir, input_bits):
 
 
 simulate_ext = simulate
+
+
+def simulate_mk(cir, input_bits):
+    """simulate() plus the 3-gen three-input AND (3gen_mk_gates.jl:55-64)."""
+    from . import AND3
+    v = np.zeros(cir.n_wires(), bool)
+    v[:cir.n_inputs] = np.asarray(input_bits, bool)
+    for gi, (op, a, b, c) in enumerate(cir.gates):
+        o = cir.n_inputs + gi
+        if op == AND3:
+            v[o] = v[a] and v[b] and v[c]
+        else:
+            one = Circuit()
+            one.n_inputs = o
+            one.gates = [(op, a, b, c)]
+            v[o] = simulate(one, v[:o])[o]
+    return v
 
 
 # ---- evaluator --------------------------------------------------------------------------------------------------------
