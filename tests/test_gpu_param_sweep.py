@@ -56,3 +56,30 @@ def test_multi_key_shapes(O, shape, monkeypatch):
     assert np.array_equal(ck.gates(thfhe.AND3, ca, cb, cc), orc.gates(O.AND3, ca, cb, cc)), shape
     assert np.array_equal(ck.gates(thfhe.MUX, ca, cb, cc), orc.gates(O.MUX, ca, cb, cc)), shape
     ck.close()
+
+
+@pytest.mark.parametrize("name", ["SK-80", "SK-128", "SK-lib"])
+def test_multi_gate_keyswitch_kernel(O, name):
+    # sk_keyswitch_multi_kernel (batches >= 1024 gates, basebit 2; 8 / 4 gates per workgroup share every row load, coordinate range
+    # cut in four, atomics): every output word against the oracle for a ragged batch, and the MUX combine (two rotations per gate)
+    import thfhe
+    p = O.make_params(name)
+    s = O.SIGMAS[name]
+    K = O.SKKeys(p, 31, s["bk"], s["ks"])
+    orc = O.Oracle(p, K.bk, K.ksk)
+    ck = thfhe.CloudKey(thfhe.make_params(name), K.bk, K.ksk, device=0)
+    rng = np.random.default_rng(17)
+    B = 1030 + 3
+    u = rng.integers(-2**31, 2**31, size=(B, p.N + 1), dtype=np.int64).astype(np.int32)
+    u[5, :p.N] = 0                                   # all digits zero except the rounding offset
+    got = ck.keyswitch(u)
+    idx = np.r_[0:40, 5, B - 9:B]                    # first workgroups, the ragged tail
+    assert np.array_equal(got[idx], np.stack([orc.keyswitch(u[i]) for i in idx]))
+    assert np.array_equal(got, ck.keyswitch(u))      # atomics: order-independent integer adds
+    a, b, c = (rng.integers(0, 2, 1024) for _ in range(3))
+    ca, cb, cc = (K.encrypt_bits(v, s["lwe"], 80 + q) for q, v in enumerate((a, b, c)))
+    out = ck.gates(thfhe.MUX, ca, cb, cc)
+    assert np.array_equal(K.decrypt_bits(out), np.where(a == 1, b, c).astype(bool))
+    pick = [0, 511, 1023]
+    assert np.array_equal(out[pick], orc.gates(O.MUX, ca[pick], cb[pick], cc[pick]))
+    ck.close()

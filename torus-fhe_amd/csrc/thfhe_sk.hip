@@ -386,6 +386,100 @@ __global__ __launch_bounds__(256) void sk_keyswitch_kernel(KSArgs a) {
 }
 
 // words per lane of a padded KSK row: smallest even W with 64*W >= n+1
+// ------------------------------------------------------------------------------------------------------
+// key switch, throughput variant (ks_basebit == 2, large batches).  sk_keyswitch_kernel reads 0.75 rows per gate and (i, j) out of
+// L2 -- 15.7 MB per gate, 64 GB per 4096-gate launch: it is bound by L2 bandwidth, not by its subtractions.  Here one workgroup
+// takes G gates and walks (i, j) once for all of them: the three rows KS[i][j][1..3] are loaded ONCE into registers (3 x W words per
+// lane) and every gate subtracts the row its wave-uniform digit selects (or nothing), so a launch pulls 3/G rows per gate and (i, j)
+// (G = 16: 4x less).  Wave w takes coordinates i = w (mod 4); the four partial sums per gate are combined with integer atomics into the
+// zeroed output (adds commute: bit-exact).
+// ------------------------------------------------------------------------------------------------------
+template <int NX4, int NX2, int G>
+__global__ __launch_bounds__(256) void sk_keyswitch_multi_kernel(KSArgs a) {
+    constexpr int W = 4 * NX4 + 2 * NX2;  // words per lane of a padded row
+    constexpr int ROW = 64 * W;
+    __shared__ uint32_t sA[G][1024];
+    const long g0 = (long)blockIdx.x * G;
+    const int ng = (a.gates - g0) < G ? (int)(a.gates - g0) : G;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const uint32_t prec_offset = 1u << (32 - (1 + 2 * a.t));
+    const int span = 1024 / a.nsplit, first = (int)blockIdx.y * span;
+    for (int q = tid; q < G * span; q += 256) {
+        const int g = q / span, i = first + q % span;
+        uint32_t v = 0;
+        if (g < ng) {
+            const int32_t *u1 = a.u + (size_t)(g0 + g) * a.rot_per_gate * 1025;
+            v = (uint32_t)u1[i];
+            if (a.rot_per_gate == 2) v += (uint32_t)u1[1025 + i];
+            v += prec_offset;
+        }
+        sA[g][i] = v;  // absent gates: all digits zero
+    }
+    __syncthreads();
+    uint32_t r[G][W];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int q = 0; q < W; q++) r[g][q] = 0;
+    const int i_lo = (int)blockIdx.y * (1024 / a.nsplit), i_hi = i_lo + 1024 / a.nsplit;
+    for (int i = i_lo + wave; i < i_hi; i += 4) {
+        uint32_t ai[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) ai[g] = __builtin_amdgcn_readfirstlane(sA[g][i]);
+        const int32_t *rowi = a.ksk + (size_t)i * a.t * 3 * ROW;
+        for (int j = 0; j < a.t; j++) {
+            const int sh = 32 - 2 * (j + 1);
+            uint32_t x[3][W];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const int32_t *row = rowi + ((size_t)j * 3 + d) * ROW;
+#pragma unroll
+                for (int c = 0; c < NX4; c++) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(row + c * 256 + 4 * lane);
+                    x[d][4 * c] = v.x, x[d][4 * c + 1] = v.y, x[d][4 * c + 2] = v.z, x[d][4 * c + 3] = v.w;
+                }
+                if (NX2 > 0) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(row + NX4 * 256 + 2 * lane);
+                    x[d][4 * NX4] = v.x, x[d][4 * NX4 + 1] = v.y;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const uint32_t d = (ai[g] >> sh) & 3u;  // wave-uniform
+                if (d == 1) {
+#pragma unroll
+                    for (int q = 0; q < W; q++) r[g][q] -= x[0][q];
+                } else if (d == 2) {
+#pragma unroll
+                    for (int q = 0; q < W; q++) r[g][q] -= x[1][q];
+                } else if (d == 3) {
+#pragma unroll
+                    for (int q = 0; q < W; q++) r[g][q] -= x[2][q];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        if (g < ng) {  // (no `break`: the loop must unroll completely so that r[][] stays in registers)
+            const int32_t *u1 = a.u + (size_t)(g0 + g) * a.rot_per_gate * 1025;
+            unsigned int *out = reinterpret_cast<unsigned int *>(a.out) + (size_t)(g0 + g) * (a.n + 1);
+            uint32_t b = 0;
+            if (wave == 0 && blockIdx.y == 0) {
+                b = (uint32_t)u1[1024];
+                if (a.rot_per_gate == 2) b += (uint32_t)u1[1025 + 1024] + (1u << 29);
+            }
+#pragma unroll
+            for (int q = 0; q < W; q++) {
+                const int col = q < 4 * NX4 ? (q >> 2) * 256 + 4 * lane + (q & 3) : NX4 * 256 + 2 * lane + (q - 4 * NX4);
+                uint32_t v = r[g][q];
+                if (col == a.n) v += b;
+                if (col <= a.n) atomicAdd(out + col, v);
+            }
+        }
+    }
+}
+
 inline int ks_words_per_lane(int n) { return (((n + 1 + 63) / 64) + 1) & ~1; }
 
 __global__ __launch_bounds__(256) void sk_linear_kernel(const int32_t *__restrict__ in0, int32_t *__restrict__ out, size_t words, int negate) {
@@ -405,6 +499,7 @@ struct thfhe_ctx {
     cplx *d_bk = nullptr;     // spectral key
     int32_t *d_ksk = nullptr; // padded rows
     int ks_w = 0;             // words per lane of a padded KSK row
+    long ks_multi_min_gates = 1024;  // batches of at least this many gates use sk_keyswitch_multi_kernel (rows shared by the gates of a workgroup)
     int coop_max_jobs = 1024;  // batches up to this many rotations use the cooperative (latency) kernel (measured crossover ~1150)
     cplx *d_tw = nullptr;
     // workspace
@@ -488,6 +583,24 @@ int enqueue_rotations(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1
 }
 
 int enqueue_keyswitch(thfhe_ctx *c, const int32_t *d_u, int32_t *d_out, size_t gates, int rot_per_gate, bool timed) {
+    if (c->p.ks_basebit == 2 && (long)gates >= c->ks_multi_min_gates && (c->ks_w == 8 || c->ks_w == 10 || c->ks_w == 18)) {
+        // throughput variant: the gates of a workgroup share every row load; the coordinate range is cut in four so that 2048+ workgroups
+        // keep ~12 waves per CU in flight (measured on MI355X, 4096 gates, n = 630: 1.75 ms against 2.57 ms for one gate per workgroup;
+        // G = 16 or row double-buffering bring nothing more -- the loop is bound by its uniform-branch row selection, not by L2 any more)
+        constexpr int kSplit = 4;
+        KSArgs k{c->d_ksk, d_u, d_out, (long)gates, rot_per_gate, c->p.n, c->p.ks_t, 2, kSplit};
+        THFHE_HIP(hipMemsetAsync(d_out, 0, gates * (size_t)(c->p.n + 1) * sizeof(int32_t), c->stream));
+        const dim3 block(256);
+        if (c->ks_w == 8) hipLaunchKernelGGL((sk_keyswitch_multi_kernel<2, 0, 8>), dim3((unsigned)((gates + 7) / 8), kSplit), block, 0, c->stream, k);
+        else if (c->ks_w == 10) hipLaunchKernelGGL((sk_keyswitch_multi_kernel<2, 1, 8>), dim3((unsigned)((gates + 7) / 8), kSplit), block, 0, c->stream, k);
+        else hipLaunchKernelGGL((sk_keyswitch_multi_kernel<4, 1, 4>), dim3((unsigned)((gates + 3) / 4), kSplit), block, 0, c->stream, k);
+        if (timed && c->profiling) {
+            THFHE_HIP(hipEventRecord(c->ev[3], c->stream));
+            c->ev_valid = true;
+        }
+        THFHE_HIP(hipGetLastError());
+        return THFHE_OK;
+    }
     const int nsplit = gates <= 32 ? 16 : (gates <= 128 ? 8 : (gates <= 512 ? 2 : 1));  // fill the chip at small batch sizes
     KSArgs k{c->d_ksk, d_u, d_out, (long)gates, rot_per_gate, c->p.n, c->p.ks_t, c->p.ks_basebit, nsplit};
     if (nsplit > 1) THFHE_HIP(hipMemsetAsync(d_out, 0, gates * (size_t)(c->p.n + 1) * sizeof(int32_t), c->stream));
