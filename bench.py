@@ -104,7 +104,10 @@ def cpu_baseline(K, p_name, xa, xb, gpu_out, sample):
     ref = orc.gates(O.NAND, xa[:sample], xb[:sample])
     dt = time.perf_counter() - t0
     exact = bool(np.array_equal(ref, gpu_out[:sample]))
-    return dict(value=sample / dt, unit="gates/s", cores=threads, kind="port",
+    t1 = time.perf_counter()
+    orc.gates(O.NAND, xa[:1], xb[:1])           # one gate = one OpenMP task: the single-thread figure SURVEY.md 8(d) asks for
+    dt1 = time.perf_counter() - t1
+    return dict(value=sample / dt, unit="gates/s", cores=threads, kind="port", single_thread_value=1.0 / dt1,
                 sample=f"first {sample} NAND gates of the same batch, exact-integer oracle (64-bit NTT path, not libtfhe's AVX FFT), "
                        f"OpenMP schedule(dynamic) over gates on {threads} threads, {dt:.2f} s wall",
                 gpu_bit_exact_on_sample=exact)
