@@ -96,3 +96,36 @@ def test_concurrent_boots_calls_are_batched_and_correct(O):
         assert np.array_equal(got[idx], ref), names[op]
     L.thfhe_tfhe_forget_key.restype = None
     L.thfhe_tfhe_forget_key(ck)
+
+
+def test_cpp_client_links_and_matches_oracle(O, tmp_path):
+    """tests/cpp/evaluate_demo.cpp: a plain g++ program written like the reference's C++ callers (Evaluate of src/Convert.cpp:28-33 from
+    OpenMP threads, FullAdder of src/KNN_medical_data.cpp:134-157 with in-place carries), built against include/tfhe_shim.h and LINKED
+    with libthfhe_hip.so in the place of libtfhe; outputs must equal the oracle bit for bit."""
+    import os
+    import subprocess
+    from conftest import full_adder, threaded_multi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-s", "-B", "-C", os.path.join(root, "tests", "cpp")], check=True)
+    p = O.make_params("SK-128", n=40)
+    K = O.SKKeys(p, 33, 2.0**-25, 2.0**-15)
+    orc = O.Oracle(p, K.bk, K.ksk)
+    nbits = 8
+    x, y = 0xB5, 0x6E
+    bits = lambda v: [(v >> (nbits - 1 - i)) & 1 for i in range(nbits)]          # MSB first, as the reference
+    c1, c2 = K.encrypt_bits(bits(x), 2.0**-15, 61), K.encrypt_bits(bits(y), 2.0**-15, 62)
+    cin = K.encrypt_bits([0], 2.0**-15, 63)[0]
+    hdr = np.array([p.n, p.N, p.l, p.Bgbit, p.ks_t, p.ks_basebit, nbits], np.int32)
+    blob_in, blob_out = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(blob_in, "wb") as f:
+        for arr in (hdr, K.bk, K.ksk, c1, c2, cin):
+            f.write(np.ascontiguousarray(arr, np.int32).tobytes())
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    r = subprocess.run([os.path.join(root, "tests", "cpp", "evaluate_demo"), str(blob_in), str(blob_out)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = np.fromfile(blob_out, np.int32).reshape(3, nbits, p.n + 1)
+    assert np.array_equal(out[0], orc.gates(O.AND, c1, c2))
+    ref_sum, ref_carry = full_adder(threaded_multi(orc.gates), c1, c2, cin)
+    assert np.array_equal(out[1], ref_sum) and np.array_equal(out[2], ref_carry)
+    val = lambda rec: int("".join("1" if b else "0" for b in K.decrypt_bits(rec)), 2)
+    assert val(out[0]) == (x & y) and val(out[1]) == (x + y) & 0xFF
