@@ -291,3 +291,74 @@ def test_mk_dag_executor_on_gpu(O):
     enc = K.encrypt_bits([1, 0, 1, 1, 0, 1, 1, 0, 0], sg["lwe"], 99)
     assert np.array_equal(Cc.evaluate(ck, c2, enc), Cc.evaluate_levels(ck, c2, enc))
     ck.close()
+
+
+def random_dag(rng, n_inputs, n_gates, ops):
+    from thfhe import circuits as Cc
+    import thfhe
+    cir = Cc.Circuit()
+    cir.inputs(n_inputs)
+    for _ in range(n_gates):
+        op = int(rng.choice(ops))
+        w = cir.n_wires()
+        pick = lambda: int(rng.integers(max(0, w - 12), w))       # mostly recent wires: deep chains and wide levels both occur
+        if op in (thfhe.NOT, thfhe.COPY):
+            cir.gate(op, pick())
+        elif op in (thfhe.MUX, thfhe.AND3):
+            cir.gate(op, pick(), pick(), pick())
+        else:
+            cir.gate(op, pick(), pick())
+    return cir
+
+
+def test_scheduler_levels_respect_dependencies_on_random_dags():
+    # the Python ASAP schedule (the native one is checked against it on the GPU): every gate runs after its operands
+    import thfhe
+    rng = np.random.default_rng(11)
+    ops = [thfhe.NAND, thfhe.XOR, thfhe.OR, thfhe.ANDNY, thfhe.MUX, thfhe.NOT, thfhe.COPY]
+    for trial in range(5):
+        cir = random_dag(rng, 5, 120, ops)
+        seen = set(range(cir.n_inputs))
+        for level in cir.levels():
+            linear = cir.gates[level[0]][0] in (thfhe.NOT, thfhe.COPY)
+            done_now = set()
+            for g in level:
+                for w in cir.gates[g][1:]:
+                    assert w < 0 or w in seen or (linear and w in done_now), (trial, g)
+                done_now.add(cir.n_inputs + g)
+            seen |= done_now
+        assert len(seen) == cir.n_wires()
+
+
+@pytest.mark.gpu
+def test_native_dag_executors_on_random_dags(O):
+    # thfhe_dag_run / thfhe_mk_dag_run on random gate DAGs (all gate classes, NOT / COPY chains, shared operands): every wire decrypts to
+    # the plaintext simulation, and the single-key result equals the host-driven level loop bit for bit
+    import thfhe
+    from thfhe import keygen, circuits as Cc
+    rng = np.random.default_rng(12)
+    p = thfhe.make_params("SK-128", n=64)
+    K = keygen.SecretKeySet(p, seed=4)
+    ck = thfhe.CloudKey(p, K.bk, K.ksk, device=0)
+    sk_ops = [thfhe.NAND, thfhe.OR, thfhe.AND, thfhe.XOR, thfhe.XNOR, thfhe.NOR, thfhe.ANDNY, thfhe.ANDYN, thfhe.ORNY, thfhe.ORYN,
+              thfhe.MUX, thfhe.NOT, thfhe.COPY]
+    for trial in range(3):
+        cir = random_dag(rng, 6, 150, sk_ops)
+        bits = rng.integers(0, 2, 6)
+        enc = K.encrypt(bits, seed=100 + trial)
+        stats = {}
+        vals = Cc.evaluate(ck, cir, enc, stats)
+        assert np.array_equal(K.decrypt(vals), Cc.simulate(cir, bits)), trial
+        assert np.array_equal(vals, Cc.evaluate_levels(ck, cir, enc)), trial
+        assert stats["levels"] == cir.census()["depth"]
+    ck.close()
+    pm = O.make_params("MK2", n=64)
+    sg = O.SIGMAS["MK2"]
+    KM = O.MKKeys(pm, 5, sg["bk"], sg["ks"])
+    mk = thfhe.MKCloudKey(thfhe.make_params(**pm.as_dict()), KM.bk, KM.ksk, device=0)
+    mk_ops = [thfhe.NAND, thfhe.OR, thfhe.AND, thfhe.XOR, thfhe.AND3, thfhe.MUX, thfhe.NOT, thfhe.COPY]
+    cir = random_dag(rng, 6, 80, mk_ops)
+    bits = rng.integers(0, 2, 6)
+    vals = Cc.evaluate(mk, cir, KM.encrypt_bits(bits, sg["lwe"], 7))
+    assert np.array_equal(KM.decrypt_bits(vals), Cc.simulate_mk(cir, bits))
+    mk.close()
