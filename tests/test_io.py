@@ -18,3 +18,20 @@ def test_roundtrip_of_reference_fixture(tmp_path, O):
     ph = (recs[:, -1].astype(np.int64) - (recs[:, :-1].astype(np.int64) * key).sum(axis=1)) % 2**32
     bits = ph < 2**31          # phase > 0
     assert O.bits_to_int_msb_first(bits) == 9876
+
+
+def test_seeded_lwe_key_regeneration_matches_the_reference_fixture_key():
+    # thfhe.keygen.lwe_key_from_seed restates std::seed_seq + std::default_random_engine + uniform_int_distribution<int32_t>(0,1) as
+    # libstdc++ implements them: with the reference's seed {100, 20032, 21341} (src/bootstrap_modules.cpp:52-55) it must reproduce the key
+    # that oracle/gen_fixture_key.cpp (the C++ original) printed -- the key under which the reference's committed fixtures decrypt
+    import os
+    import numpy as np
+    from thfhe import io, keygen
+    here = os.path.dirname(os.path.abspath(__file__))
+    ref = np.array([int(c) for c in open(os.path.join(here, "golden", "fixture_lwe_key.txt")).read().strip()], np.int32)
+    key = keygen.lwe_key_from_seed([100, 20032, 21341], 630)
+    assert np.array_equal(key, ref)
+    recs, _ = io.read_ciphertexts(os.path.join(here, "golden", "cloud1.data"), 630)
+    phase = (recs[:, -1].astype(np.int64) - (recs[:, :-1].astype(np.int64) * key).sum(axis=1)).astype(np.uint32).view(np.int32)
+    assert int("".join("1" if v > 0 else "0" for v in phase), 2) == 9876          # test/bootstrap_modules/plain1.txt
+    assert not np.array_equal(keygen.lwe_key_from_seed([100, 20032, 21342], 630), ref)

@@ -75,6 +75,52 @@ def gen_keyswitch_key(rng, in_key, out_key, t, basebit, sigma):
     return ksk
 
 
+def seed_seq_generate(seeds, count):
+    """std::seed_seq(seeds).generate: `count` 32-bit words ([rand.util.seedseq], as libstdc++ implements it)."""
+    v = [int(x) & 0xFFFFFFFF for x in seeds]
+    n, s = count, len(v)
+    b = [0x8B8B8B8B] * n
+    t = 11 if n >= 623 else 7 if n >= 68 else 5 if n >= 39 else 3 if n >= 7 else (n - 1) // 2
+    p, q = (n - t) // 2, (n - t) // 2 + t
+    T = lambda x: (x ^ (x >> 27)) & 0xFFFFFFFF
+    for k in range(max(s + 1, n)):
+        r1 = (1664525 * T(b[k % n] ^ b[(k + p) % n] ^ b[(k - 1) % n])) & 0xFFFFFFFF
+        r2 = (r1 + (s if k == 0 else (k % n + v[k - 1]) if k <= s else k % n)) & 0xFFFFFFFF
+        b[(k + p) % n] = (b[(k + p) % n] + r1) & 0xFFFFFFFF
+        b[(k + q) % n] = (b[(k + q) % n] + r2) & 0xFFFFFFFF
+        b[k % n] = r2
+    for k in range(max(s + 1, n), max(s + 1, n) + n):
+        r3 = (1566083941 * T((b[k % n] + b[(k + p) % n] + b[(k - 1) % n]) & 0xFFFFFFFF)) & 0xFFFFFFFF
+        r4 = (r3 - k % n) & 0xFFFFFFFF
+        b[(k + p) % n] ^= r3
+        b[(k + q) % n] ^= r4
+        b[k % n] = r4
+    return b
+
+
+def lwe_key_from_seed(seeds, n):
+    """The LWE secret key a libtfhe program draws first after `tfhe_random_generator_setSeed(seeds, len)`: n draws of
+    std::uniform_int_distribution<int32_t>(0, 1) on std::default_random_engine (minstd_rand0) seeded from std::seed_seq(seeds)
+    -- libstdc++'s algorithms.  With the reference's seed {100, 20032, 21341} (src/bootstrap_modules.cpp:52-55, src/libthfhe.cpp:362-363)
+    this is the key under which its committed fixtures test/bootstrap_modules/*.data decrypt."""
+    M = 2147483647                                    # minstd_rand0: x <- 16807 x mod (2^31 - 1), values in [1, M-1]
+    x = seed_seq_generate(seeds, 4)[3] % M            # linear_congruential_engine::seed(Sseq&): generates k + 3 = 4 words, uses the last
+    if x == 0:
+        x = 1
+    urng_range = M - 2                                # max - min of the engine
+    scaling = urng_range // 2                         # uniform_int_distribution, urange = 1 < urngrange: rejection + downscaling
+    past = 2 * scaling
+    key = np.empty(n, np.int32)
+    for i in range(n):
+        while True:
+            x = (16807 * x) % M
+            ret = x - 1
+            if ret < past:
+                break
+        key[i] = ret // scaling
+    return key
+
+
 class SecretKeySet:
     """Single-key secret material + the cloud-key tables the engine consumes."""
 
