@@ -38,7 +38,9 @@ def algorithmic_bytes(p, rotations=1):
 
 
 def dist_setup(n_gpus):
-    """torch.distributed over RCCL ("nccl") when launched by torch.distributed.run; returns (rank, world, barrier, max_reduce)."""
+    """torch.distributed over RCCL ("nccl") when launched by torch.distributed.run; returns (rank, world, barrier, max_reduce, backend).
+    The backend is chosen ONCE from the environment (THFHE_BENCH_BACKEND, default nccl; "gloo" for CPU rehearsals) and a failure
+    of it is fatal on every rank -- a rank that quietly switched backends would leave the others hanging in the first collective."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world == 1:
@@ -46,35 +48,35 @@ def dist_setup(n_gpus):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    import torch
+    import torch   # before libthfhe_hip.so is loaded: both then share torch's HIP runtime (thfhe.lib() enforces the same order)
     import torch.distributed as dist
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     backend = os.environ.get("THFHE_BENCH_BACKEND", "nccl")
-    dev = None
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit(f"[bench] THFHE_BENCH_BACKEND={backend!r}: expected nccl or gloo")
     # RCCL / gloo print start-up banners on the C-level stdout: keep stdout clean for the single JSON line
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    if backend == "nccl":
-        try:
+    try:
+        if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=rank, world_size=world)
             dev = torch.device("cuda", local)
             t = torch.zeros(1, device=dev)
             dist.all_reduce(t)  # forces communicator creation outside the timed region
             torch.cuda.synchronize()
-        except Exception as e:  # RCCL unavailable (e.g. CPU rehearsal): the timing barrier falls back to gloo
-            print(f"[bench] rank {rank}: nccl backend unavailable ({e!r}); using gloo for the timing barrier", file=sys.stderr)
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            backend = "gloo"
-    if backend == "gloo":
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        dev = torch.device("cpu")
-        dist.barrier()
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    os.close(saved_stdout)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dev = torch.device("cpu")
+            dist.barrier()
+    except Exception as e:
+        print(f"[bench] rank {rank}: {backend} backend failed to initialise: {e!r}", file=sys.stderr, flush=True)
+        os._exit(3)   # non-zero on this rank; the launcher tears the others down
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     def barrier():
         if dev.type == "cuda":
@@ -89,28 +91,67 @@ def dist_setup(n_gpus):
     return rank, world, barrier, max_reduce, backend
 
 
-def cpu_baseline(K, p_name, xa, xb, gpu_out, sample):
-    """Time the CPU oracle (exact-integer restatement of the reference path, OpenMP over gates) on the first
-    `sample` gates of the same workload, on this host's cores; also cross-check the GPU output on them."""
+def cpu_baseline(K, p_name, xa, xb, gpu_out, per_thread):
+    """Time the CPU oracle (exact-integer restatement of the reference path, OpenMP over gates = the reference's only parallel
+    pattern, src/KNN_medical_data.cpp:681) on the first gates of the same workload, on the CPUs this process may really use
+    (affinity mask capped by the cgroup quota); median of 3 runs; also cross-check the GPU output on the sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    cores = len(os.sched_getaffinity(0))
-    os.environ["OMP_NUM_THREADS"] = str(cores)  # one oracle thread per core this process may run on (set before libgomp loads)
     import oracle_lib as O
+    threads = O.usable_cpus()
     p = O.make_params(p_name)
     orc = O.Oracle(p, K.bk, K.ksk)
-    threads = O.lib().oracle_max_threads()
-    orc.gates(O.NAND, xa[:1], xb[:1])  # warm the NTT tables
-    t0 = time.perf_counter()
-    ref = orc.gates(O.NAND, xa[:sample], xb[:sample])
-    dt = time.perf_counter() - t0
+    L = O.lib()
+    L.oracle_set_threads(threads)
+    sample = min(per_thread * threads, xa.shape[0])
+    orc.gates(O.NAND, xa[:threads], xb[:threads])   # warm the NTT tables and every thread's scratch arena
+    runs = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ref = orc.gates(O.NAND, xa[:sample], xb[:sample])
+        runs.append(time.perf_counter() - t0)
+    dt = sorted(runs)[1]
     exact = bool(np.array_equal(ref, gpu_out[:sample]))
-    t1 = time.perf_counter()
-    orc.gates(O.NAND, xa[:1], xb[:1])           # one gate = one OpenMP task: the single-thread figure SURVEY.md 8(d) asks for
-    dt1 = time.perf_counter() - t1
-    return dict(value=sample / dt, unit="gates/s", cores=threads, kind="port", single_thread_value=1.0 / dt1,
-                sample=f"first {sample} NAND gates of the same batch, exact-integer oracle (64-bit NTT path, not libtfhe's AVX FFT), "
-                       f"OpenMP schedule(dynamic) over gates on {threads} threads, {dt:.2f} s wall",
+    L.oracle_set_threads(1)
+    n1 = min(4, sample)
+    one = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        orc.gates(O.NAND, xa[:n1], xb[:n1])
+        one.append((time.perf_counter() - t0) / n1)
+    L.oracle_set_threads(threads)
+    single = 1.0 / sorted(one)[1]
+    value = sample / dt
+    return dict(value=value, unit="gates/s", cores=threads, threads=threads, kind="port",
+                per_thread_gates_per_s=value / threads, single_thread_value=single, scaling_efficiency=value / (threads * single),
+                affinity_cpus=len(os.sched_getaffinity(0)), runs_s=[round(r, 3) for r in runs],
+                sample=f"first {sample} NAND gates of the same batch ({per_thread} per thread), exact-integer oracle (64-bit NTT engine, per-thread "
+                       f"scratch, no allocation in the CMux loop; NOT libtfhe's AVX FFT), OpenMP schedule(dynamic) over gates on {threads} threads "
+                       f"(cgroup CPU quota; the affinity mask shows {len(os.sched_getaffinity(0))}), median of 3 runs = {dt:.2f} s",
                 gpu_bit_exact_on_sample=exact)
+
+
+def load_counters(param_set, batch, kernel):
+    """The committed per-launch PMC counters of this workload (profiles/*_counters.json, written by tools/summarize_profile.py from
+    tools/profile_bench.sh runs; bench.py cannot run rocprofv3 on itself).  They are used only if they were measured on exactly the kernel
+    sources of this tree (sha256, tools/kernel_hash.py), for this parameter set, batch size and kernel; otherwise -> (None, reason)."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_hash import kernel_source_hash
+    want = kernel_source_hash()
+    stale = 0
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), key=os.path.getmtime, reverse=True):
+        try:
+            c = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        if c.get("param_set") != param_set or c.get("gates_per_launch") != batch or c.get("kernel") != kernel:
+            continue
+        if c.get("kernel_source_sha256") != want:
+            stale += 1
+            continue
+        return c, os.path.relpath(path, ROOT)
+    return None, (f"{stale} counter file(s) for this workload are stale (kernel sources changed since they were measured): traffic / fractions withheld"
+                  if stale else "no committed counter file for this workload")
 
 
 def main():
@@ -121,7 +162,7 @@ def main():
     ap.add_argument("--set", default="SK-128")
     ap.add_argument("--batch", type=int, default=4096, help="gates per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="gates in the CPU baseline sample (0 = 8 per host thread)")
+    ap.add_argument("--cpu-per-thread", type=int, default=8, help="gates per host thread in the CPU baseline sample")
     args = ap.parse_args()
 
     import thfhe
@@ -182,8 +223,42 @@ def main():
     ab = algorithmic_bytes(p)
     value = world * B * args.steps / elapsed
     br_avg_ms = float(np.mean(br_ms))
+    br_s = br_avg_ms * 1e-3
     br_bytes = B * (ab["bk"] + 2 * words * 4 + (p.N + 1) * 4)  # blind-rotate launch: key stream + records in, extracted out
-    br_achieved = br_bytes / (br_avg_ms * 1e-3) / 1e9
+    kernel = ((("mk_blind_rotate_coop2k_kernel" if p.N == 2048 else
+                ("mk_blind_rotate_pair_kernel" if (p.l <= 3 and B > 256) else "mk_blind_rotate_coop_kernel")) + f"<{p.l}>") if mk
+              else (f"sk_blind_rotate_ring_kernel<{p.l}>" if B > 1024 else f"sk_blind_rotate_coop_kernel<{p.l}>"))
+    # SURVEY.md 8(d)'s HBM model, kept under its own name: it charges every gate a private pass over the transformed key, while the kernels
+    # share each key chunk between the gates of a workgroup and all workgroups hit L2 / Infinity Cache -- it can exceed 1 and bounds nothing
+    hbm_alg = {"bytes_per_launch": br_bytes, "achieved_gbs": br_bytes / br_s / 1e9, "peak_gbs": HBM_PEAK_GBS,
+               "frac": br_bytes / br_s / 1e9 / HBM_PEAK_GBS,
+               "whole_gate": {"bytes_per_gate": ab["total"], "achieved_gbs": value / world * ab["total"] / 1e9,
+                              "frac": value / world * ab["total"] / 1e9 / HBM_PEAK_GBS},
+               "note": "algorithmic bytes = SURVEY.md 8(d) per-gate figure x gates per launch; NOT a bound for these kernels (see hbm_measured_frac)"}
+    roof = {"kernel": kernel, "avg_launch_ms": br_avg_ms, "keyswitch_avg_launch_ms": float(np.mean(ks_ms)),
+            "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+            "hbm_measured_frac": None, "fp64_issue_frac": None, "lds_busy": None, "hbm_algorithmic": hbm_alg}
+    counters, why = load_counters(args.set, B, kernel)
+    roof["counters_source"] = why
+    if counters is not None:
+        from summarize_profile import FP64_PEAK_GINST, FP64_PEAK_TFLOPS, derive
+        d = derive(counters, br_s)   # counters of the same kernel sources and workload, combined with the launch time measured in THIS run
+        roof.update({k: d.get(k) for k in ("traffic", "hbm_measured_frac", "fp64_issue_frac", "lds_busy")})
+        cand = {"fp64_valu_issue": d.get("fp64_issue_frac"), "lds": d.get("lds_busy"), "hbm": d.get("hbm_measured_frac")}
+        cand = {k: v for k, v in cand.items() if v is not None}
+        if cand:
+            roof["bound"] = max(cand, key=cand.get)
+        if roof["bound"] == "fp64_valu_issue":
+            # instruction roofline of the binding pipe: wave64 FP64 instructions issued per second against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
+            roof.update(achieved=d["fp64_ginst_per_s"], peak=FP64_PEAK_GINST, unit="Ginst/s (wave64 FP64 VALU instructions)", frac=d["fp64_issue_frac"],
+                        fp64_tflops={"achieved": d.get("fp64_tflops"), "peak": FP64_PEAK_TFLOPS, "frac": d.get("fp64_flop_frac"),
+                                     "note": "flop view of the same pipe (FMA = 2 flop, add / mul = 1): lower than the issue fraction because the "
+                                             "butterflies of the transform are unfused adds"})
+        elif roof["bound"] == "lds":
+            roof.update(achieved=d["lds_busy"], peak=1.0, unit="LDS-array busy fraction", frac=d["lds_busy"])
+        elif roof["bound"] == "hbm":
+            roof.update(achieved=d["traffic"] / br_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=d["hbm_measured_frac"])
+        roof["effective_clock_ghz_at_profile"] = d.get("effective_clock_ghz")
     res = {
         "metric": "bootstrapped gates/sec (NAND, N=1024)", "value": value, "unit": "gates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -193,29 +268,11 @@ def main():
                                f"(P={p.parties}, n={p.n}, N={p.N}, k={p.k}, l={p.l}, Bgbit={p.Bgbit}, ks {p.ks_t}/{p.ks_basebit}), keys+ciphertexts resident in HBM",
                    "gates_per_gpu_per_step": B, "param_set": args.set, "parallelism": f"gate-batch sharding x{world}, replicated keys",
                    "timing_backend": backend},
-        "roofline": {"bound": "hbm", "kernel": (("mk_blind_rotate_coop2k_kernel" if p.N == 2048 else
-                                 ("mk_blind_rotate_pair_kernel" if (p.l <= 3 and B > 256) else "mk_blind_rotate_coop_kernel")) + f"<{p.l}>") if mk
-                               else (f"sk_blind_rotate_ring_kernel<{p.l}>" if B > 1024 else f"sk_blind_rotate_coop_kernel<{p.l}>"),
-                     "achieved": br_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": br_achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": br_bytes, "avg_launch_ms": br_avg_ms,
-                     "note": "algorithmic bytes count the whole transformed key once per gate (SURVEY.md 8d); the kernels share every key chunk between "
-                             "the gates of a workgroup (8 single-key / 2 multi-key) and all workgroups hit L2/Infinity Cache, so frac is not bounded by 1 "
-                             "(measured HBM traffic: profiles/)",
-                     "keyswitch_avg_launch_ms": float(np.mean(ks_ms)),
-                     "whole_gate": {"bytes_per_gate": ab["total"],
-                                    "achieved": value / world * ab["total"] / 1e9,
-                                    "frac": value / world * ab["total"] / 1e9 / HBM_PEAK_GBS}},
+        "roofline": roof,
         "bit_exact_decrypt_errors": errors,
     }
-    tfile = os.path.join(ROOT, "profiles", "traffic_sk128.json")
-    if not mk and args.set == "SK-128" and B == 4096 and os.path.exists(tfile):
-        # HBM bytes per blind-rotate launch from the committed PMC passes of this same workload (bench.py cannot run rocprofv3 on itself)
-        res["roofline"]["traffic"] = json.load(open(tfile))["traffic_bytes_per_launch"]
-        res["roofline"]["traffic_source"] = "profiles/traffic_sk128.json"
     if world == 1 and not args.no_cpu_baseline and not mk:
-        threads = len(os.sched_getaffinity(0))
-        sample = args.cpu_sample or max(8, 8 * min(threads, 64))
-        res["cpu_baseline"] = cpu_baseline(K, args.set, xa, xb, out, min(sample, B))
+        res["cpu_baseline"] = cpu_baseline(K, args.set, xa, xb, out, args.cpu_per_thread)
     print(json.dumps(res), flush=True)
 
 

@@ -21,6 +21,23 @@
 
 typedef unsigned __int128 u128;
 
+/* per-thread scratch arena: the hot loop (n CMuxes per gate) allocates nothing -- one growing buffer per call site and
+ * thread, kept for the life of the thread (OpenMP workers persist), so `oracle_gates` scales with the host's cores
+ * instead of serialising on the allocator */
+enum { SCR_MUX = 0, SCR_EXT_DIG, SCR_EXT_NTT, SCR_EXT_PROD, SCR_BOOT, SCR_KS, SCR_GATE, SCR_MKMUX, SCR_MKEXT_DIG, SCR_MKEXT_NTT,
+       SCR_MKEXT_PROD, SCR_MKBOOT, SCR_MKKS, SCR_MKGATE, SCR_SLOTS };
+static __thread void *scr_ptr[SCR_SLOTS];
+static __thread size_t scr_cap[SCR_SLOTS];
+static void *scr(int slot, size_t bytes) {
+    if (scr_cap[slot] < bytes) {
+        free(scr_ptr[slot]);
+        scr_ptr[slot] = malloc(bytes);
+        if (!scr_ptr[slot]) abort();
+        scr_cap[slot] = bytes;
+    }
+    return scr_ptr[slot];
+}
+
 /* ============================================================================================
  * Goldilocks field  p = 2^64 - 2^32 + 1
  * ========================================================================================== */
@@ -287,6 +304,14 @@ int oracle_max_threads(void) {
     return 1;
 #endif
 }
+/* the caller knows the CPU share it really has (affinity mask AND cgroup quota); OpenMP only sees the affinity mask */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* ============================================================================================
  * single-key context
@@ -326,10 +351,10 @@ void oracle_ctx_destroy(oracle_ctx *c) {
 /* tgsw_extern_mul: out[c] = sum_{j,p} digit_p(tmp[j]) (*) BK_i[j*l+p][c]     J/tgsw.jl:146-156 */
 static void extern_mul32(const oracle_ctx *c, int32_t i, const int32_t *tmp, int32_t *out, int use_schoolbook) {
     const int N = c->p.N, k = c->p.k, l = c->p.l, rows = (k + 1) * l;
-    int32_t *dig = (int32_t *)malloc(sizeof(int32_t) * (size_t)rows * N);
+    int32_t *dig = (int32_t *)scr(SCR_EXT_DIG, sizeof(int32_t) * (size_t)rows * N);
     for (int j = 0; j <= k; j++) oracle_decompose32(tmp + (size_t)j * N, N, l, c->p.Bgbit, dig + (size_t)j * l * N);
     if (use_schoolbook) {
-        int32_t *prod = (int32_t *)malloc(sizeof(int32_t) * N);
+        int32_t *prod = (int32_t *)scr(SCR_EXT_PROD, sizeof(int32_t) * N);
         memset(out, 0, sizeof(int32_t) * (size_t)(k + 1) * N);
         for (int r = 0; r < rows; r++)
             for (int cc = 0; cc <= k; cc++) {
@@ -338,10 +363,9 @@ static void extern_mul32(const oracle_ctx *c, int32_t i, const int32_t *tmp, int
                 for (int j = 0; j < N; j++)
                     out[(size_t)cc * N + j] = (int32_t)((uint32_t)out[(size_t)cc * N + j] + (uint32_t)prod[j]);
             }
-        free(prod);
     } else {
         const gl_tables *T = gl_get_tables(N);
-        uint64_t *d = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(rows + k + 1) * N), *acc = d + (size_t)rows * N;
+        uint64_t *d = (uint64_t *)scr(SCR_EXT_NTT, sizeof(uint64_t) * (size_t)(rows + k + 1) * N), *acc = d + (size_t)rows * N;
         for (int r = 0; r < rows; r++) {
             for (int j = 0; j < N; j++) d[(size_t)r * N + j] = gl_from_i64(dig[(size_t)r * N + j]);
             gl_ntt_fwd(d + (size_t)r * N, T);
@@ -358,16 +382,14 @@ static void extern_mul32(const oracle_ctx *c, int32_t i, const int32_t *tmp, int
             gl_ntt_inv(a, T);
             for (int j = 0; j < N; j++) out[(size_t)cc * N + j] = (int32_t)(uint32_t)(uint64_t)gl_to_centered(a[j]);
         }
-        free(d);
     }
-    free(dig);
 }
 
 /* mux_rotate: acc += BK_i (.) (X^barai * acc - acc)        J/bootstrap.jl:19-23 */
 void oracle_mux_rotate(const oracle_ctx *c, int32_t i, int32_t barai, int32_t *acc, int use_schoolbook) {
     const int N = c->p.N, k = c->p.k;
     size_t sz = (size_t)(k + 1) * N;
-    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * 2 * sz), *ext = tmp + sz;
+    int32_t *tmp = (int32_t *)scr(SCR_MUX, sizeof(int32_t) * 2 * sz), *ext = tmp + sz;
     for (int j = 0; j <= k; j++) {
         oracle_mul_by_monomial32(acc + (size_t)j * N, barai, N, tmp + (size_t)j * N);
         for (int q = 0; q < N; q++)
@@ -375,7 +397,6 @@ void oracle_mux_rotate(const oracle_ctx *c, int32_t i, int32_t barai, int32_t *a
     }
     extern_mul32(c, i, tmp, ext, use_schoolbook);
     for (size_t q = 0; q < sz; q++) acc[q] = (int32_t)((uint32_t)acc[q] + (uint32_t)ext[q]);
-    free(tmp);
 }
 
 /* rlwe_extract_sample: a'_0 = a_0, a'_j = -a_{N-j}, b' = body_0     J/rlwe.jl:64-68, J/polynomials.jl:69-72 */
@@ -393,8 +414,8 @@ void oracle_bootstrap_wo_keyswitch(const oracle_ctx *c, int32_t mu, const int32_
     const int N = c->p.N, k = c->p.k, n = c->p.n;
     int32_t barb = oracle_modswitch(x[n], N);
     size_t sz = (size_t)(k + 1) * N;
-    int32_t *acc = (int32_t *)calloc(sz, sizeof(int32_t));
-    int32_t *tv = (int32_t *)malloc(sizeof(int32_t) * N);
+    int32_t *acc = (int32_t *)scr(SCR_BOOT, sizeof(int32_t) * (sz + N)), *tv = acc + sz;
+    memset(acc, 0, sizeof(int32_t) * sz);
     for (int j = 0; j < N; j++) tv[j] = mu;
     oracle_mul_by_monomial32(tv, -barb, N, acc + (size_t)k * N); /* acc = (0, X^{-barb} * testvect) */
     for (int i = 0; i < n; i++) {
@@ -402,8 +423,6 @@ void oracle_bootstrap_wo_keyswitch(const oracle_ctx *c, int32_t mu, const int32_
         if (bara != 0) oracle_mux_rotate(c, i, bara, acc, use_schoolbook);
     }
     extract32(acc, N, k, out);
-    free(tv);
-    free(acc);
 }
 
 /* keyswitch      J/keyswitch.jl:45-80 */
@@ -411,7 +430,8 @@ static void keyswitch_with(const int32_t *ksk, int Nin, int n, int t, int basebi
     const int base = 1 << basebit;
     const uint32_t mask = (uint32_t)base - 1u;
     const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
-    uint32_t *res = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
+    uint32_t *res = (uint32_t *)scr(SCR_KS, sizeof(uint32_t) * ((size_t)n + 1));
+    memset(res, 0, sizeof(uint32_t) * (size_t)n);
     res[n] = (uint32_t)b_init;
     for (int i = 0; i < Nin; i++) {
         uint32_t aibar = (uint32_t)in[i] + prec_offset;
@@ -424,7 +444,6 @@ static void keyswitch_with(const int32_t *ksk, int Nin, int n, int t, int basebi
         }
     }
     memcpy(out, res, sizeof(uint32_t) * ((size_t)n + 1));
-    free(res);
 }
 void oracle_keyswitch(const oracle_ctx *c, const int32_t *in, int32_t *out) {
     const int Nin = c->p.N * c->p.k;
@@ -481,7 +500,7 @@ int oracle_gates(const oracle_ctx *c, int op, const int32_t *in0, const int32_t 
     /* one thread per gate: the reference's only parallel pattern (src/KNN_medical_data.cpp:681) */
 #pragma omp parallel for schedule(dynamic)
     for (long g = 0; g < (long)count; g++) {
-        int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (rec + 2 * ((size_t)Nk + 1)));
+        int32_t *tmp = (int32_t *)scr(SCR_GATE, sizeof(int32_t) * (rec + 2 * ((size_t)Nk + 1)));
         int32_t *u1 = tmp + rec, *u2 = u1 + Nk + 1;
         const int32_t *x = in0 + g * rec, *y = in1 + g * rec, *z = in2 ? in2 + g * rec : NULL;
         if (op != OR_GATE_MUX) {
@@ -497,7 +516,6 @@ int oracle_gates(const oracle_ctx *c, int op, const int32_t *in0, const int32_t 
             u1[Nk] = (int32_t)((uint32_t)u1[Nk] + (uint32_t)MU);
             oracle_keyswitch(c, u1, res + g * rec);
         }
-        free(tmp);
     }
     memcpy(out, res, sizeof(int32_t) * count * rec);
     free(res);
@@ -550,14 +568,14 @@ void oracle_mk_ctx_destroy(oracle_mk_ctx *c) {
 static void mk_extern_mul(const oracle_mk_ctx *c, int party, int i, const int64_t *tmp, int64_t *out, int use_schoolbook) {
     const int N = c->p.N, l = c->p.l;
     const size_t key_off = ((size_t)party * c->p.n + i) * 4 * l; /* in polynomials */
-    int64_t *dig = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)l * N);
+    int64_t *dig = (int64_t *)scr(SCR_MKEXT_DIG, sizeof(int64_t) * 2 * (size_t)l * N);
     int64_t *g_c1 = dig, *g_c0 = dig + (size_t)l * N;
     oracle_decompose64(tmp, N, l, c->p.Bgbit, g_c1);     /* tmp[0] = c1 (mask) */
     oracle_decompose64(tmp + N, N, l, c->p.Bgbit, g_c0); /* tmp[1] = c0 (body) */
     /* which part multiplies which digit set, per output: out[1]=c0' : (g_c0,P1) (g_c1,P2); out[0]=c1' : (g_c0,P4) (g_c1,P3) */
     const int part_for[2][2] = {{3, 2}, {0, 1}}; /* [out poly][0: g_c0, 1: g_c1] -> part index 0..3 */
     if (use_schoolbook) {
-        int64_t *prod = (int64_t *)malloc(sizeof(int64_t) * N);
+        int64_t *prod = (int64_t *)scr(SCR_MKEXT_PROD, sizeof(int64_t) * N);
         memset(out, 0, sizeof(int64_t) * 2 * (size_t)N);
         for (int o = 0; o < 2; o++)
             for (int w = 0; w < 2; w++)
@@ -567,10 +585,9 @@ static void mk_extern_mul(const oracle_mk_ctx *c, int party, int i, const int64_
                     oracle_polymul_schoolbook64(d, row, N, prod);
                     for (int j = 0; j < N; j++) out[(size_t)o * N + j] = (int64_t)((uint64_t)out[(size_t)o * N + j] + (uint64_t)prod[j]);
                 }
-        free(prod);
     } else {
         const gl_tables *T = gl_get_tables(N);
-        uint64_t *d = (uint64_t *)malloc(sizeof(uint64_t) * (2 * (size_t)l + 2) * N);
+        uint64_t *d = (uint64_t *)scr(SCR_MKEXT_NTT, sizeof(uint64_t) * (2 * (size_t)l + 2) * N);
         uint64_t *alo = d + 2 * (size_t)l * N, *ahi = alo + N;
         for (int r = 0; r < 2 * l; r++) {
             for (int j = 0; j < N; j++) d[(size_t)r * N + j] = gl_from_i64(dig[(size_t)r * N + j]);
@@ -594,22 +611,19 @@ static void mk_extern_mul(const oracle_mk_ctx *c, int party, int i, const int64_
             for (int j = 0; j < N; j++)
                 out[(size_t)o * N + j] = (int64_t)((uint64_t)gl_to_centered(alo[j]) + ((uint64_t)gl_to_centered(ahi[j]) << 32));
         }
-        free(d);
     }
-    free(dig);
 }
 
 /* mk_mux_rotate_3gen      J/3gen_mk_internals.jl:59-62 */
 void oracle_mk_mux_rotate(const oracle_mk_ctx *c, int32_t party, int32_t i, int32_t barai, int64_t *acc, int use_schoolbook) {
     const int N = c->p.N;
-    int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * 4 * (size_t)N), *ext = tmp + 2 * (size_t)N;
+    int64_t *tmp = (int64_t *)scr(SCR_MKMUX, sizeof(int64_t) * 4 * (size_t)N), *ext = tmp + 2 * (size_t)N;
     for (int m = 0; m < 2; m++) {
         oracle_mul_by_monomial64(acc + (size_t)m * N, barai, N, tmp + (size_t)m * N);
         for (int q = 0; q < N; q++) tmp[(size_t)m * N + q] = (int64_t)((uint64_t)tmp[(size_t)m * N + q] - (uint64_t)acc[(size_t)m * N + q]);
     }
     mk_extern_mul(c, party, i, tmp, ext, use_schoolbook);
     for (int q = 0; q < 2 * N; q++) acc[q] = (int64_t)((uint64_t)acc[q] + (uint64_t)ext[q]);
-    free(tmp);
 }
 
 /* mk_bootstrap_wo_keyswitch_3gen / mk_blind_rotate_and_extract_3gen / mk_blind_rotate_3gen
@@ -617,8 +631,8 @@ void oracle_mk_mux_rotate(const oracle_mk_ctx *c, int32_t party, int32_t i, int3
 void oracle_mk_bootstrap_wo_keyswitch(const oracle_mk_ctx *c, int64_t mu, const int32_t *x, int32_t *out, int use_schoolbook) {
     const int N = c->p.N, n = c->p.n, P = c->p.parties;
     int32_t barb = oracle_modswitch(x[(size_t)n * P], N);
-    int64_t *acc = (int64_t *)calloc(2 * (size_t)N, sizeof(int64_t));
-    int64_t *tv = (int64_t *)malloc(sizeof(int64_t) * N);
+    int64_t *acc = (int64_t *)scr(SCR_MKBOOT, sizeof(int64_t) * 3 * (size_t)N), *tv = acc + 2 * (size_t)N;
+    memset(acc, 0, sizeof(int64_t) * 2 * (size_t)N);
     for (int j = 0; j < N; j++) tv[j] = mu;
     oracle_mul_by_monomial64(tv, -barb, N, acc + N);
     for (int p = 0; p < P; p++) /* parties outer, key index inner */
@@ -629,15 +643,13 @@ void oracle_mk_bootstrap_wo_keyswitch(const oracle_mk_ctx *c, int64_t mu, const 
     out[0] = oracle_t64tot32(acc[0]);
     for (int j = 1; j < N; j++) out[j] = oracle_t64tot32((int64_t)(0ull - (uint64_t)acc[N - j]));
     out[N] = oracle_t64tot32(acc[N]);
-    free(tv);
-    free(acc);
 }
 
 /* mk_keyswitch_3gen       J/mk_internals.jl:730-744 */
 void oracle_mk_keyswitch(const oracle_mk_ctx *c, const int32_t *in, int32_t *out) {
     const int N = c->p.N, n = c->p.n, P = c->p.parties, t = c->p.ks_t, bb = c->p.ks_basebit;
     const size_t per_party = (size_t)N * t * ((1 << bb) - 1) * ((size_t)n + 1);
-    int32_t *part = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    int32_t *part = (int32_t *)scr(SCR_MKKS, sizeof(int32_t) * ((size_t)n + 1));
     uint32_t b = (uint32_t)in[N];
     for (int p = 0; p < P; p++) {
         keyswitch_with(c->ksk + (size_t)p * per_party, N, n, t, bb, in, 0, part); /* keyswitch(ks[p], (a, 0)) */
@@ -645,7 +657,6 @@ void oracle_mk_keyswitch(const oracle_mk_ctx *c, const int32_t *in, int32_t *out
         b += (uint32_t)part[n];
     }
     out[(size_t)n * P] = (int32_t)b;
-    free(part);
 }
 
 int oracle_mk_gates(const oracle_mk_ctx *c, int op, const int32_t *in0, const int32_t *in1, const int32_t *in2,
@@ -663,7 +674,7 @@ int oracle_mk_gates(const oracle_mk_ctx *c, int op, const int32_t *in0, const in
     int32_t *res = (int32_t *)malloc(sizeof(int32_t) * count * rec);
 #pragma omp parallel for schedule(dynamic)
     for (long g = 0; g < (long)count; g++) {
-        int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (2 * rec + (size_t)N + 1));
+        int32_t *tmp = (int32_t *)scr(SCR_MKGATE, sizeof(int32_t) * (2 * rec + (size_t)N + 1));
         int32_t *t2 = tmp + rec, *u = t2 + rec;
         const int32_t *x = in0 + g * rec, *y = in1 + g * rec, *z = in2 ? in2 + g * rec : NULL;
         if (op == OR_GATE_AND3) { /* J/3gen_mk_gates.jl:55-64 */
@@ -690,7 +701,6 @@ int oracle_mk_gates(const oracle_mk_ctx *c, int op, const int32_t *in0, const in
             oracle_mk_bootstrap_wo_keyswitch(c, MU, tmp, u, use_schoolbook);
             oracle_mk_keyswitch(c, u, res + g * rec);
         }
-        free(tmp);
     }
     memcpy(out, res, sizeof(int32_t) * count * rec);
     free(res);
@@ -1082,7 +1092,7 @@ void oracle_ccs_bootstrap_wo_keyswitch(const oracle_ccs_ctx *c, int32_t mu, cons
 void oracle_ccs_keyswitch(const oracle_ccs_ctx *c, const int32_t *in, int32_t *out) {
     const int N = c->p.N, n = c->p.n, P = c->p.parties, t = c->p.ks_t, bb = c->p.ks_basebit;
     const size_t per_party = (size_t)N * t * ((1 << bb) - 1) * ((size_t)n + 1);
-    int32_t *part = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    int32_t *part = (int32_t *)scr(SCR_MKKS, sizeof(int32_t) * ((size_t)n + 1));
     uint32_t b = (uint32_t)in[(size_t)P * N];
     for (int p = 0; p < P; p++) {
         keyswitch_with(c->ksk + (size_t)p * per_party, N, n, t, bb, in + (size_t)p * N, 0, part);
@@ -1090,7 +1100,6 @@ void oracle_ccs_keyswitch(const oracle_ccs_ctx *c, const int32_t *in, int32_t *o
         b += (uint32_t)part[n];
     }
     out[(size_t)n * P] = (int32_t)b;
-    free(part);
 }
 /* mk_gate_nand (J/mk_gates.jl:7-13) and, with the same bootstrap, the other two-input linear prologues of J/gates.jl */
 int oracle_ccs_gates(const oracle_ccs_ctx *c, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count, int use_schoolbook) {

@@ -130,6 +130,7 @@ void oracle_partial_decrypt(const int32_t *key_share, const int32_t *tlwe_a, con
 int32_t oracle_final_decrypt(const int32_t *tlwe_b, const int32_t *partials /*[t][N]*/, int32_t t, int32_t N, int32_t *result);
 
 int oracle_max_threads(void);
+void oracle_set_threads(int n); /* OpenMP team size for the batch entry points */
 
 #ifdef __cplusplus
 }

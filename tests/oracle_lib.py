@@ -124,12 +124,36 @@ def lib():
         "oracle_partial_decrypt": (None, [i32p, i32p, i32p, C.c_int32, i32p]),
         "oracle_final_decrypt": (C.c_int32, [i32p, i32p, C.c_int32, C.c_int32, i32p]),
         "oracle_max_threads": (C.c_int, []),
+        "oracle_set_threads": (None, [C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
+    if "OMP_NUM_THREADS" not in os.environ:
+        L.oracle_set_threads(usable_cpus())
     _lib = L
     return L
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota.  (The GPU boxes show 256 CPUs in the
+    mask under a 16-CPU quota; an OpenMP team of 256 there just time-slices 16 cores.)"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def p32(a):

@@ -101,3 +101,30 @@ def test_new_entry_points_validate_arguments_without_a_device():
         with pytest.raises(thfhe.ThfheError):
             from thfhe import threshold
             threshold.PolyContext(0)
+
+
+def test_multi_rank_processes_load_torch_before_the_engine():
+    """Runtime-order rule: torch bundles its own HIP runtime, and loading libthfhe_hip.so first hides the GPU
+    from torch.  thfhe.lib() therefore imports torch itself in a multi-rank job (WORLD_SIZE > 1) -- and does not in a single process."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import thfhe; assert 'torch' not in sys.modules; thfhe.lib(); "
+            "print(int('torch' in sys.modules), int(bool(thfhe.torch_loaded_first)))") % os.path.join(ROOT, "torus-fhe_amd")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "THFHE_TORCH_FIRST")}
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, WORLD_SIZE="2"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["1", "1"]
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["0", "0"]
+
+
+def test_operand_batches_of_different_length_are_rejected():
+    # the C side copies x.shape[0] records from every operand (ADVICE r1): the host layer must refuse a shorter one
+    import thfhe
+    x, y = np.zeros((3, 631), np.int32), np.zeros((2, 631), np.int32)
+    with pytest.raises(ValueError):
+        thfhe._same_count(x, y)
+    with pytest.raises(ValueError):
+        thfhe._same_count(x, x, np.zeros(2, np.int32))
+    thfhe._same_count(x, x, None)

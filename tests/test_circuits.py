@@ -218,6 +218,60 @@ def test_reduced_knn_decision_on_gpu():
     ck.close()
 
 
+@pytest.mark.gpu
+def test_reference_sized_knn_decision_on_gpu(O):
+    """BASELINE.json configs[3] at the reference's size: the whole KNN decision of src/KNN_medical_data.cpp:676-732 for one test
+    record -- 5 train rows x 14 columns x 32 bit, the first six records of the reference's data1.csv (tests/golden/data1.csv):
+    ~1.26e5 blind rotations in ~1e3 levels through the native DAG executor.  Every wire must decrypt to the plaintext simulation,
+    >= 200 sampled gates (two-input and MUX) must equal the oracle bit for bit, and the sorted distances / vote count / decision
+    must equal the plaintext KNN."""
+    import os
+    import thfhe
+    from thfhe import keygen, circuits as Cc
+    nb, ncol, ntrain = 32, 14, 5
+    rows = []
+    with open(os.path.join(O.GOLDEN, "data1.csv")) as f:
+        next(f)
+        for line in f:
+            rows.append([int(float(w)) & 0xFFFFFFFF for w in line.strip().split(",")][:ncol])   # the reference reads every field into an int
+            if len(rows) == ntrain + 1:
+                break
+    train, test_row = rows[:ntrain], rows[ntrain]
+    threshold = ntrain // 2
+    cir, decision, count, sdists = build_knn(nb, ncol, ntrain)
+    cs = cir.census()
+    assert 1.2e5 < cs["rotations"] < 1.3e5
+    p = thfhe.make_params("SK-128")
+    K = keygen.SecretKeySet(p, seed=0x5EED0001)
+    ck = thfhe.CloudKey(p, K.bk, K.ksk, device=0)
+    plain = knn_plain_inputs(nb, test_row, train, threshold)
+    stats = {}
+    vals = Cc.evaluate(ck, cir, K.encrypt(np.array(plain), seed=0x5EED0002), stats)
+    sim = Cc.simulate(cir, plain)
+    assert np.array_equal(K.decrypt(vals), sim)                       # all ~1.02e5 wires
+    d = [sum(abs(test_row[c] - r[c]) for c in range(1, ncol - 1)) & 0xFFFFFFFF for r in train]
+    assert [from_bits(K.decrypt(vals[w])) for w in sdists] == sorted(d)
+    votes = sum(r[ncol - 1] for r in train)
+    assert from_bits(K.decrypt(vals[count])) == votes
+    assert bool(K.decrypt(vals[[decision]])[0]) == (votes > threshold)
+    assert stats["levels"] > 900 and stats["rotations"] == cs["rotations"]
+    # sampled gates against the oracle, grouped by opcode so that every group is one OpenMP batch
+    orc = O.Oracle(O.make_params("SK-128"), K.bk, K.ksk)
+    rng = np.random.default_rng(11)
+    gates = np.array(cir.gates, np.int64)
+    two = np.flatnonzero(gates[:, 0] != thfhe.MUX)
+    mux = np.flatnonzero(gates[:, 0] == thfhe.MUX)
+    pick = np.concatenate([rng.choice(two, 176, replace=False), rng.choice(mux, 48, replace=False)])
+    base = cir.n_inputs
+    for op in np.unique(gates[pick, 0]):
+        g = pick[gates[pick, 0] == op]
+        x, y = vals[gates[g, 1]], vals[gates[g, 2]]
+        z = vals[gates[g, 3]] if op == thfhe.MUX else None
+        ref = orc.gates(int(op), x, y, z)
+        assert np.array_equal(vals[base + g], ref), f"opcode {op}: sampled DAG gates differ from the oracle"
+    ck.close()
+
+
 def test_mk_comparison_and_multiplier_circuits_plaintext():
     # J/3gen_mk_gates.jl:258-362 (bit vectors LSB-first, two's complement comparisons)
     from thfhe import circuits as Cc

@@ -26,9 +26,42 @@ static_assert(offsetof(TFheGateBootstrappingCloudKeySet, bk) == 8 && offsetof(TF
 
 namespace {
 
+// The device context is cached per key-set ADDRESS.  A libtfhe client may delete a key set and load another one at the same
+// address, so every entry carries a cheap fingerprint of the key it was built from (table pointers, shape, a few key words);
+// a mismatch rebuilds the device tables instead of evaluating under a stale key.
+struct Fingerprint {
+    const void *bk_rows, *ks_rows;
+    int32_t n, N, l, Bgbit, ks_t, ks_basebit;
+    uint32_t words[8];
+    bool operator==(const Fingerprint &o) const {
+        if (bk_rows != o.bk_rows || ks_rows != o.ks_rows || n != o.n || N != o.N || l != o.l || Bgbit != o.Bgbit || ks_t != o.ks_t ||
+            ks_basebit != o.ks_basebit)
+            return false;
+        for (int q = 0; q < 8; q++)
+            if (words[q] != o.words[q]) return false;
+        return true;
+    }
+};
+Fingerprint fingerprint(const TFheGateBootstrappingCloudKeySet *bk) {
+    const LweBootstrappingKey *b = bk->bk;
+    Fingerprint f{};
+    f.bk_rows = b->bk;
+    f.ks_rows = b->ks->ks;
+    f.n = b->in_out_params->n, f.N = b->accum_params->N, f.l = b->bk_params->l, f.Bgbit = b->bk_params->Bgbit;
+    f.ks_t = b->ks->t, f.ks_basebit = b->ks->basebit;
+    const int rows = (b->accum_params->k + 1) * f.l;
+    for (int q = 0; q < 4; q++) {  // first / last TGSW sample, first / last row, a body and a mask coefficient each
+        const TGswSample &s = b->bk[q < 2 ? 0 : f.n - 1];
+        const TLweSample &r = s.all_sample[(q & 1) ? rows - 1 : 0];
+        f.words[2 * q] = (uint32_t)r.a[0].coefsT[q];
+        f.words[2 * q + 1] = (uint32_t)r.a[b->accum_params->k].coefsT[f.N - 1 - q];
+    }
+    return f;
+}
 struct Entry {
     thfhe_ctx *ctx;
     int n;
+    Fingerprint fp;
 };
 std::mutex g_mu;
 std::map<const TFheGateBootstrappingCloudKeySet *, Entry> g_ctx;
@@ -41,8 +74,13 @@ std::map<const TFheGateBootstrappingCloudKeySet *, Entry> g_ctx;
 
 Entry get_ctx(const TFheGateBootstrappingCloudKeySet *bk) {
     std::lock_guard<std::mutex> g(g_mu);
+    const Fingerprint fp = fingerprint(bk);
     auto it = g_ctx.find(bk);
-    if (it != g_ctx.end()) return it->second;
+    if (it != g_ctx.end()) {
+        if (it->second.fp == fp) return it->second;
+        thfhe_ctx_destroy(it->second.ctx);  // another key set now lives at this address (serialises behind running calls: ctx mutex)
+        g_ctx.erase(it);
+    }
     const LweBootstrappingKey *b = bk->bk;
     thfhe_params p{};
     p.n = b->in_out_params->n;
@@ -73,7 +111,7 @@ Entry get_ctx(const TFheGateBootstrappingCloudKeySet *bk) {
                 for (int q = 0; q < p.n; q++) dst[q] = s->a[q];
                 dst[p.n] = s->b;
             }
-    Entry e{nullptr, p.n};
+    Entry e{nullptr, p.n, fp};
     const char *dev = std::getenv("THFHE_DEVICE");
     if (thfhe_ctx_create(&p, bkc.data(), ksk.data(), dev ? std::atoi(dev) : 0, &e.ctx) != THFHE_OK) die("cannot create device context");
     g_ctx[bk] = e;
@@ -244,6 +282,23 @@ int thfhe_tfhe_gate_batch(int op, LweSample *result, const LweSample *ca, const 
     return THFHE_OK;
 }
 void thfhe_tfhe_forget_key(const TFheGateBootstrappingCloudKeySet *bk) {
+    // first retire the batcher: wait until no leader is executing on this key's context and nobody is queued
+    Batcher *B = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_bmu);
+        auto it = g_batchers.find(bk);
+        if (it != g_batchers.end()) {
+            B = it->second;
+            g_batchers.erase(it);
+        }
+    }
+    if (B) {
+        {
+            std::unique_lock<std::mutex> lk(B->m);
+            B->cv.wait(lk, [&] { return !B->leader_active && B->queue.empty(); });
+        }
+        delete B;
+    }
     std::lock_guard<std::mutex> g(g_mu);
     auto it = g_ctx.find(bk);
     if (it != g_ctx.end()) {

@@ -286,7 +286,10 @@ int thfhe_ccs_ctx_create(const thfhe_params *p, const int32_t *bk, const int32_t
     c->words = p->parties * p->n;
     c->w_pad = (c->words + 3) & ~3;
     c->row_words = 128 * ((p->n + 1 + 127) / 128);
+    int32_t *d_coeff = nullptr, *d_raw = nullptr;  // upload staging, freed on every path
     auto fail = [&](int code) {
+        (void)hipFree(d_coeff);
+        (void)hipFree(d_raw);
         thfhe_ccs_ctx_destroy(c);
         return code;
     };
@@ -303,7 +306,6 @@ int thfhe_ccs_ctx_create(const thfhe_params *p, const int32_t *bk, const int32_t
     struct Tab { const int32_t *src; long npolys; cplx **dst; };
     const Tab tabs[3] = {{bk, (long)p->parties * p->n * 3 * p->l, &c->d_bk}, {pk, (long)p->parties * p->l, &c->d_pk}, {crs, (long)p->l, &c->d_crs}};
     for (const Tab &t : tabs) {
-        int32_t *d_coeff = nullptr;
         CK(hipMalloc(&d_coeff, (size_t)t.npolys * 1024 * sizeof(int32_t)));
         CK(hipMemcpyAsync(d_coeff, t.src, (size_t)t.npolys * 1024 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         CK(hipMalloc(t.dst, (size_t)t.npolys * 1024 * sizeof(cplx)));
@@ -311,9 +313,9 @@ int thfhe_ccs_ctx_create(const thfhe_params *p, const int32_t *bk, const int32_t
         CK(hipGetLastError());
         CK(hipStreamSynchronize(c->stream));
         (void)hipFree(d_coeff);
+        d_coeff = nullptr;
     }
     const long rows = (long)p->parties * 1024 * p->ks_t * ((1 << p->ks_basebit) - 1);
-    int32_t *d_raw = nullptr;
     CK(hipMalloc(&d_raw, (size_t)rows * (p->n + 1) * sizeof(int32_t)));
     CK(hipMemcpyAsync(d_raw, ksk, (size_t)rows * (p->n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     CK(hipMalloc(&c->d_ksk, (size_t)rows * c->row_words * sizeof(int32_t)));

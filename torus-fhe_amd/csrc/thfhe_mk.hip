@@ -613,7 +613,11 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     c->w_pad = (c->words + 3) & ~3;
     c->row_words = 128 * ((p->n + 1 + 127) / 128);
     c->log2_2n = ilog2(2 * p->N);
+    int64_t *d_coeff = nullptr;  // upload staging, freed on every path
+    int32_t *d_raw = nullptr;
     auto fail = [&](int code) {
+        (void)hipFree(d_coeff);
+        (void)hipFree(d_raw);
         thfhe_mk_ctx_destroy(c);
         return code;
     };
@@ -637,7 +641,6 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     CK(hipMemcpyAsync(c->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
     const long PN = (long)p->parties * p->n;
     const size_t coeff_words = (size_t)PN * 4 * p->l * p->N;
-    int64_t *d_coeff = nullptr;
     CK(hipMalloc(&d_coeff, coeff_words * sizeof(int64_t)));
     CK(hipMemcpyAsync(d_coeff, bk_coeff, coeff_words * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     const size_t chunks = (size_t)PN * 2 * p->l * 8;
@@ -651,7 +654,6 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     }
     CK(hipGetLastError());
     const long rows = (long)p->parties * p->N * p->ks_t * ((1 << p->ks_basebit) - 1);
-    int32_t *d_raw = nullptr;
     CK(hipMalloc(&d_raw, (size_t)rows * (p->n + 1) * sizeof(int32_t)));
     CK(hipMemcpyAsync(d_raw, ksk, (size_t)rows * (p->n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     CK(hipMalloc(&c->d_ksk, (size_t)rows * c->row_words * sizeof(int32_t)));
@@ -721,12 +723,14 @@ int thfhe_mk_sync(thfhe_mk_ctx *c) {
 }
 int thfhe_mk_set_profiling(thfhe_mk_ctx *c, int enabled) {
     if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
     c->profiling = enabled != 0;
     c->ev_valid = false;
     return THFHE_OK;
 }
 int thfhe_mk_last_timings(thfhe_mk_ctx *c, float ms[4]) {
     if (!c || !ms) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
     if (!c->ev_valid) return thfhe_fail(THFHE_E_INVALID, "no profiled call recorded");
     THFHE_HIP(hipEventSynchronize(c->ev[3]));
     THFHE_HIP(hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));

@@ -102,6 +102,28 @@ __global__ __launch_bounds__(256) void sk_prologue_kernel(const int32_t *__restr
     }
 }
 
+#ifdef THFHE_STAMPS
+// Diagnostic build only (make stamps -> torus-fhe_amd/lib/libthfhe_hip_stamps.so, never shipped): per-wave cycle totals of the phases of
+// the ring kernel's CMux loop, s_memtime deltas summed over all CMuxes; read back with thfhe_debug_read_stamps.
+__device__ unsigned long long g_stamps[8 * 2048 * 8];
+#define STAMP_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime()
+#define STAMP(slot)                                              \
+    do {                                                         \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        st_acc[slot] += now_ - st_t;                             \
+        st_t = now_;                                             \
+    } while (0)
+#define STAMP_FLUSH(wg, wave)                                                                                  \
+    do {                                                                                                       \
+        if (lane == 0 && (wg) < 2048)                                                                          \
+            for (int q_ = 0; q_ < 6; q_++) g_stamps[(((size_t)(wg)) * 8 + (wave)) * 8 + q_] = st_acc[q_];       \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(slot)
+#define STAMP_FLUSH(wg, wave)
+#endif
+
 // arguments of the blind-rotate kernels
 struct BRArgs {
     const cplx *bk;        // spectral key
@@ -130,7 +152,7 @@ struct BRArgs {
 // three chunks are in flight under every forward transform.  Per row: 5 barriers, 4 DMA issues per wave.
 // A wave whose mod-switched mask word is 0 (J/bootstrap.jl:40) or that has no job still streams and synchronises.
 // ------------------------------------------------------------------------------------------------------
-template <int L>
+template <int L, int V = 0>
 __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) {
     __shared__ cplx sT1[512];
     __shared__ int32_t sAcc[8][2048];
@@ -169,6 +191,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
     issue();
     issue();
     int slot_use = 0;
+    STAMP_DECL;
 
     for (int i = 0; i < a.n; i++) {
         const int ai = bara[i];                      // wave-uniform
@@ -190,16 +213,58 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
                 digits_to_z(t, (r % L) + 1, Bgbit, z);
                 wave_fft_fwd_s(lane, z, xb, sT1, w64);
             }
+            STAMP(0);  // rotate + decompose + forward transform
+            if (V == 1) {
+                // software-pipelined multiply: the key reads of a half chunk (4 slices) are in flight under the 16 FMAs of the half
+                // chunk before it, so the LDS latency of the ring reads hides behind this wave's own FP64 work instead of stalling it
+                cplx bA[4], bB[4];
 #pragma unroll
-            for (int c4 = 0; c4 < 4; c4++) {
-                // publish chunk: own slice landed (c4 == 0: two younger DMAs in flight, else one), then everybody
-                if (c4 == 0) ring_barrier<2>(); else ring_barrier<1>();
-                if (c4 > 0) issue();  // the slot of the chunk consumed before this barrier is free
-                if (active) mac8_lean(lane, S[c4 >> 1][c4 & 1], z, &sRing[slot_use][0]);
-                slot_use = slot_use == 2 ? 0 : slot_use + 1;
+                for (int c4 = 0; c4 < 4; c4++) {
+                    if (c4 == 0) ring_barrier<2>(); else ring_barrier<1>();
+                    STAMP(1);
+                    if (c4 > 0) issue();
+                    const cplx *B = &sRing[slot_use][0];
+                    if (active) {
+#pragma unroll
+                        for (int m = 0; m < 4; m++) bA[m] = B[m * 64 + lane];
+                        if (c4 > 0) {
+#pragma unroll
+                            for (int m = 0; m < 4; m++) cfma(S[(c4 - 1) >> 1][(c4 - 1) & 1][4 + m], z[4 + m], bB[m]);
+                        }
+#pragma unroll
+                        for (int m = 0; m < 4; m++) bB[m] = B[(4 + m) * 64 + lane];
+#pragma unroll
+                        for (int m = 0; m < 4; m++) cfma(S[c4 >> 1][c4 & 1][m], z[m], bA[m]);
+                    }
+                    slot_use = slot_use == 2 ? 0 : slot_use + 1;
+                    STAMP(2);
+                }
+                ring_barrier<2>();
+                issue();
+                STAMP(1);
+                if (active) {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) cfma(S[1][1][4 + m], z[4 + m], bB[m]);
+                }
+                STAMP(2);
+            } else {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) {
+                    // publish chunk: own slice landed (c4 == 0: two younger DMAs in flight, else one), then everybody
+                    if (c4 == 0) ring_barrier<2>(); else ring_barrier<1>();
+                    STAMP(1);  // waiting at the chunk barriers
+                    if (c4 > 0) issue();  // the slot of the chunk consumed before this barrier is free
+                    if (active) {
+                        if (V == 2) mac8<1>(lane, S[c4 >> 1][c4 & 1], z, &sRing[slot_use][0]);
+                        else mac8_lean(lane, S[c4 >> 1][c4 & 1], z, &sRing[slot_use][0]);
+                    }
+                    slot_use = slot_use == 2 ? 0 : slot_use + 1;
+                    STAMP(2);  // key reads + multiply-accumulate
+                }
+                ring_barrier<2>();  // the row's last chunk is consumed by all: refill its slot before the next transform
+                issue();
+                STAMP(1);
             }
-            ring_barrier<2>();  // the row's last chunk is consumed by all: refill its slot before the next transform
-            issue();
         }
         if (active) {
             wave_sync();  // every rotated read of acc precedes the updates below
@@ -211,7 +276,9 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
             }
             wave_sync();
         }
+        STAMP(3);  // inverse transforms + accumulator update
     }
+    STAMP_FLUSH(blockIdx.x, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
     if (has_job) extract16(lane, acc, acc + 1024, a.out + job * 1025);
 }
@@ -510,6 +577,9 @@ struct thfhe_ctx {
     size_t cap_stage = 0;
     int32_t *d_in[3] = {nullptr, nullptr, nullptr};
     int32_t *d_out = nullptr;
+    // gate-DAG executor: wire table and index tables (grow-only, reused by every thfhe_dag_run on this context)
+    size_t cap_wires = 0, cap_tab = 0;
+    int32_t *d_wires = nullptr, *d_tab = nullptr;
     // profiling
     bool profiling = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -551,10 +621,17 @@ int ensure_stage(thfhe_ctx *c, size_t words) {
 template <int L>
 void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
     // small batches: cooperative latency kernel (one workgroup per gate); large ones: LDS-ring kernel (eight gates per workgroup)
-    if (a.jobs <= coop_max)
+    if (a.jobs <= coop_max) {
         hipLaunchKernelGGL(sk_blind_rotate_coop_kernel<L>, dim3((unsigned)a.jobs), dim3(512), 0, s, a);
-    else
-        hipLaunchKernelGGL(sk_blind_rotate_ring_kernel<L>, dim3((unsigned)((a.jobs + 7) / 8)), dim3(512), 0, s, a);
+        return;
+    }
+    const dim3 grid((unsigned)((a.jobs + 7) / 8)), block(512);
+#ifdef THFHE_VARIANTS  // developer A/B builds only
+    static const int variant = std::getenv("THFHE_RING_VARIANT") ? std::atoi(std::getenv("THFHE_RING_VARIANT")) : 0;
+    if (L == 3 && variant == 1) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 1>), grid, block, 0, s, a); return; }
+    if (L == 3 && variant == 2) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 2>), grid, block, 0, s, a); return; }
+#endif
+    hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 0>), grid, block, 0, s, a);
 }
 
 // rotations (prologue + blind rotate) of `jobs` = gates * rot_per_gate jobs into c->d_u
@@ -670,8 +747,10 @@ int thfhe_ctx_create(const thfhe_params *p, const int32_t *bk_coeff, const int32
     c->n_pad = (p->n + 3) & ~3;
     c->ks_w = ks_words_per_lane(p->n);
     const int row_words = 64 * c->ks_w;
-    int rc = THFHE_OK;
+    int32_t *d_coeff = nullptr, *d_raw = nullptr;  // upload staging, freed on every path
     auto fail = [&](int code) {
+        (void)hipFree(d_coeff);
+        (void)hipFree(d_raw);
         thfhe_ctx_destroy(c);
         return code;
     };
@@ -689,7 +768,6 @@ int thfhe_ctx_create(const thfhe_params *p, const int32_t *bk_coeff, const int32
     CK(hipMemcpyAsync(c->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
     // bootstrapping key: upload coefficients, transform on device
     const long npolys = (long)p->n * 2 * p->l * 2;
-    int32_t *d_coeff = nullptr;
     CK(hipMalloc(&d_coeff, (size_t)npolys * 1024 * sizeof(int32_t)));
     CK(hipMemcpyAsync(d_coeff, bk_coeff, (size_t)npolys * 1024 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     CK(hipMalloc(&c->d_bk, (size_t)npolys * 1024 * sizeof(cplx)));
@@ -697,7 +775,6 @@ int thfhe_ctx_create(const thfhe_params *p, const int32_t *bk_coeff, const int32
     CK(hipGetLastError());
     // key-switching key: pad rows to 640 words
     const long rows = (long)p->N * p->ks_t * ((1 << p->ks_basebit) - 1);
-    int32_t *d_raw = nullptr;
     CK(hipMalloc(&d_raw, (size_t)rows * (p->n + 1) * sizeof(int32_t)));
     CK(hipMemcpyAsync(d_raw, ksk, (size_t)rows * (p->n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     CK(hipMalloc(&c->d_ksk, (size_t)rows * row_words * sizeof(int32_t)));
@@ -707,7 +784,6 @@ int thfhe_ctx_create(const thfhe_params *p, const int32_t *bk_coeff, const int32
     (void)hipFree(d_coeff);
     (void)hipFree(d_raw);
 #undef CK
-    (void)rc;
     *out = c;
     return THFHE_OK;
 }
@@ -715,7 +791,10 @@ int thfhe_ctx_create(const thfhe_params *p, const int32_t *bk_coeff, const int32
 void thfhe_ctx_destroy(thfhe_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    {
+        std::lock_guard<std::mutex> g(c->mu);  // a call still running on another thread finishes first
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+    }
     (void)hipFree(c->d_bk);
     (void)hipFree(c->d_ksk);
     (void)hipFree(c->d_tw);
@@ -724,6 +803,8 @@ void thfhe_ctx_destroy(thfhe_ctx *c) {
     (void)hipFree(c->d_u);
     for (auto &p : c->d_in) (void)hipFree(p);
     (void)hipFree(c->d_out);
+    (void)hipFree(c->d_wires);
+    (void)hipFree(c->d_tab);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -771,19 +852,27 @@ int thfhe_sync(thfhe_ctx *c) {
     THFHE_HIP(hipStreamSynchronize(c->stream));
     return THFHE_OK;
 }
+#ifdef THFHE_STAMPS
+int thfhe_debug_read_stamps(unsigned long long *dst, size_t count) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 int thfhe_set_coop_threshold(thfhe_ctx *c, int max_jobs) {
     if (!c || max_jobs < 0) return thfhe_fail(THFHE_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
     c->coop_max_jobs = max_jobs;
     return THFHE_OK;
 }
 int thfhe_set_profiling(thfhe_ctx *c, int enabled) {
     if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
     c->profiling = enabled != 0;
     c->ev_valid = false;
     return THFHE_OK;
 }
 int thfhe_last_timings(thfhe_ctx *c, float ms[4]) {
     if (!c || !ms) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(c->mu);
     if (!c->ev_valid) return thfhe_fail(THFHE_E_INVALID, "no profiled call recorded");
     THFHE_HIP(hipEventSynchronize(c->ev[3]));
     THFHE_HIP(hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));
@@ -857,10 +946,21 @@ int thfhe_dag_run(thfhe_ctx *c, int32_t *wires, size_t n_inputs, const int32_t *
     rc = ensure_workspace(c, plan.max_rot ? plan.max_rot : 1);
     if (!rc) rc = ensure_stage(c, plan.max_width * words);
     if (rc) return rc;
-    int32_t *d_wires = nullptr, *d_tab = nullptr;
-    const size_t wbytes = n_wires * (size_t)words * sizeof(int32_t);
-    hipError_t e = hipMalloc(&d_wires, wbytes);
-    if (e == hipSuccess) e = hipMalloc(&d_tab, plan.tab.size() * sizeof(int32_t));
+    const size_t wbytes = n_wires * (size_t)words * sizeof(int32_t), tbytes = plan.tab.size() * sizeof(int32_t);
+    hipError_t e = hipSuccess;
+    if (wbytes > c->cap_wires) {
+        (void)hipFree(c->d_wires);
+        c->d_wires = nullptr, c->cap_wires = 0;
+        e = hipMalloc(&c->d_wires, wbytes);
+        if (e == hipSuccess) c->cap_wires = wbytes;
+    }
+    if (e == hipSuccess && tbytes > c->cap_tab) {
+        (void)hipFree(c->d_tab);
+        c->d_tab = nullptr, c->cap_tab = 0;
+        e = hipMalloc(&c->d_tab, tbytes);
+        if (e == hipSuccess) c->cap_tab = tbytes;
+    }
+    int32_t *const d_wires = c->d_wires, *const d_tab = c->d_tab;
     if (e == hipSuccess) e = hipMemcpyAsync(d_wires, wires, n_inputs * (size_t)words * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_tab, plan.tab.data(), plan.tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
     rc = e == hipSuccess ? THFHE_OK : thfhe_fail_hip(e, "thfhe_dag_run setup");
@@ -890,8 +990,6 @@ int thfhe_dag_run(thfhe_ctx *c, int32_t *wires, size_t n_inputs, const int32_t *
     }
     e = hipStreamSynchronize(c->stream);
     if (rc == THFHE_OK && e != hipSuccess) rc = thfhe_fail_hip(e, "thfhe_dag_run sync");
-    (void)hipFree(d_wires);
-    (void)hipFree(d_tab);
     return rc;
 }
 

@@ -118,13 +118,34 @@ SIGNATURES = {
 }
 
 
+torch_loaded_first = None  # set by lib(): whether torch's HIP runtime was already in the process when the engine was loaded
+
+
+def _needs_torch_first():
+    """Multi-rank jobs run under torch.distributed (RCCL).  torch bundles its own HIP runtime; if libthfhe_hip.so (rpath
+    /opt/rocm/lib) is loaded BEFORE torch, torch's later-loaded runtime sees no GPU.  So in a multi-rank job -- or whenever the
+    caller asks with THFHE_TORCH_FIRST=1 -- torch is imported first, and both share torch's runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return False
+    want = os.environ.get("THFHE_TORCH_FIRST")
+    if want is None:
+        want = "1" if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 else "0"
+    return want == "1" and importlib.util.find_spec("torch") is not None
+
+
 def lib():
     """Load libthfhe_hip.so (built in-tree by __graft_entry__.build()); fail loudly if it is missing."""
-    global _lib
+    global _lib, torch_loaded_first
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ThfheError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        if _needs_torch_first():
+            import torch  # noqa: F401  (runtime-order rule above)
+        import sys
+        torch_loaded_first = "torch" in sys.modules
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)
@@ -147,6 +168,13 @@ def _rec(a, words):
     if a.shape[-1] != words:
         raise ValueError(f"expected records of {words} int32 words, got shape {a.shape}")
     return a.reshape(-1, words)
+
+
+def _same_count(x, *others):
+    """The C side copies x.shape[0] records from every operand: a shorter one would be read out of bounds."""
+    for o in others:
+        if o is not None and o.shape[0] != x.shape[0]:
+            raise ValueError(f"operand batches differ in length: {x.shape[0]} vs {o.shape[0]} records")
 
 
 class DeviceBuffer:
@@ -194,13 +222,13 @@ class CloudKey:
             raise ValueError("ksk has the wrong size for these parameters")
         h = _vp()
         _check(lib().thfhe_ctx_create(C.byref(p), _p32(bk), _p32(ks), device, C.byref(h)))
-        self.h = h
+        self.h, self._destroy = h, lib().thfhe_ctx_destroy
         self.words = p.n + 1
 
     def close(self):
-        if getattr(self, "h", None) and _lib is not None:
-            _lib.thfhe_ctx_destroy(self.h)
-        self.h = None
+        h, self.h = getattr(self, "h", None), None
+        if h and getattr(self, "_destroy", None) is not None:
+            self._destroy(h)
 
     def __del__(self):
         try:
@@ -213,6 +241,7 @@ class CloudKey:
         x = _rec(x, self.words)
         y = _rec(y, self.words) if y is not None else None
         z = _rec(z, self.words) if z is not None else None
+        _same_count(x, y, z)
         out = np.empty_like(x)
         _check(lib().thfhe_gates(self.h, op, _p32(x), _p32(y), _p32(z), _p32(out), x.shape[0]))
         return out
@@ -221,7 +250,7 @@ class CloudKey:
         """One launch for a DAG level: gate g applies ops[g] (two-input bootstrapped gates) to (x[g], y[g])."""
         x, y = _rec(x, self.words), _rec(y, self.words)
         ops = np.ascontiguousarray(ops, np.int32)
-        assert ops.shape[0] == x.shape[0] == y.shape[0]
+        _same_count(x, y, ops)
         out = np.empty_like(x)
         _check(lib().thfhe_gates_mixed(self.h, _p32(ops), _p32(x), _p32(y), _p32(out), x.shape[0]))
         return out
@@ -339,13 +368,13 @@ class MKCloudKey:
             raise ValueError("ksk has the wrong size for these parameters")
         h = _vp()
         _check(lib().thfhe_mk_ctx_create(C.byref(p), bk.ctypes.data_as(_i64p), _p32(ks), device, C.byref(h)))
-        self.h = h
+        self.h, self._destroy = h, lib().thfhe_mk_ctx_destroy
         self.words = p.parties * p.n + 1
 
     def close(self):
-        if getattr(self, "h", None) and _lib is not None:
-            _lib.thfhe_mk_ctx_destroy(self.h)
-        self.h = None
+        h, self.h = getattr(self, "h", None), None
+        if h and getattr(self, "_destroy", None) is not None:
+            self._destroy(h)
 
     def __del__(self):
         try:
@@ -357,6 +386,7 @@ class MKCloudKey:
         x = _rec(x, self.words)
         y = _rec(y, self.words) if y is not None else None
         z = _rec(z, self.words) if z is not None else None
+        _same_count(x, y, z)
         out = np.empty_like(x)
         _check(lib().thfhe_mk_gates(self.h, op, _p32(x), _p32(y), _p32(z), _p32(out), x.shape[0]))
         return out
@@ -365,6 +395,7 @@ class MKCloudKey:
         """One launch for a DAG level of two-input 3-gen gates with per-gate opcodes."""
         x, y = _rec(x, self.words), _rec(y, self.words)
         ops = np.ascontiguousarray(ops, np.int32)
+        _same_count(x, y, ops)
         out = np.empty_like(x)
         _check(lib().thfhe_mk_gates_mixed(self.h, _p32(ops), _p32(x), _p32(y), _p32(out), x.shape[0]))
         return out
@@ -434,13 +465,13 @@ class CCSCloudKey:
             raise ValueError("key table has the wrong size for these parameters")
         h = _vp()
         _check(lib().thfhe_ccs_ctx_create(C.byref(p), *[_p32(a) for a in arrs], device, C.byref(h)))
-        self.h = h
+        self.h, self._destroy = h, lib().thfhe_ccs_ctx_destroy
         self.words = p.parties * p.n + 1
 
     def close(self):
-        if getattr(self, "h", None) and _lib is not None:
-            _lib.thfhe_ccs_ctx_destroy(self.h)
-        self.h = None
+        h, self.h = getattr(self, "h", None), None
+        if h and getattr(self, "_destroy", None) is not None:
+            self._destroy(h)
 
     def __del__(self):
         try:
@@ -450,6 +481,7 @@ class CCSCloudKey:
 
     def gates(self, op, x, y):
         x, y = _rec(x, self.words), _rec(y, self.words)
+        _same_count(x, y)
         out = np.empty_like(x)
         _check(lib().thfhe_ccs_gates(self.h, op, _p32(x), _p32(y), _p32(out), x.shape[0]))
         return out

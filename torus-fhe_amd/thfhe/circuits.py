@@ -282,6 +282,7 @@ def evaluate(ck, cir, input_records, stats=None):
 
 def evaluate_levels(ck, cir, input_records, stats=None):
     """The same schedule driven from the host: one host-buffer call per level (works for single-key and multi-key contexts)."""
+    from . import AND3 as _AND3
     words = ck.words
     vals = np.zeros((cir.n_wires(), words), np.int32)
     vals[:cir.n_inputs] = np.asarray(input_records, np.int32).reshape(cir.n_inputs, words)
@@ -295,8 +296,13 @@ def evaluate_levels(ck, cir, input_records, stats=None):
                 src = vals[gates[g][1]]
                 vals[base + g] = (0 - src.astype(np.int64)).astype(np.int32) if gates[g][0] == NOT else src
             continue
-        two = [g for g in level if gates[g][0] != MUX]
+        two = [g for g in level if gates[g][0] not in (MUX, _AND3)]
         mux = [g for g in level if gates[g][0] == MUX]
+        and3 = [g for g in level if gates[g][0] == _AND3]   # 3-gen three-input AND: its own gate class (thfhe_mk_gates)
+        if and3:
+            a, b, c = (vals[[gates[g][q] for g in and3]] for q in (1, 2, 3))
+            vals[base + np.array(and3)] = ck.gates(_AND3, a, b, c)
+            launches += 1
         if two:
             ops = np.array([gates[g][0] for g in two], np.int32)
             a = vals[[gates[g][1] for g in two]]
