@@ -49,6 +49,57 @@ struct WaveS {  // the LDS-ring kernel's variant: swizzled 512-slot buffer, pass
         for (int l = 0; l < 64; l++) invs_seg3(l, z[l], xbuf, T1);
     }
 };
+struct WaveR {  // second-generation ring kernel: padded buffer, pass-1 twiddles from per-lane roots, pass-2 twiddles as powers
+    cplx T1[512], T2[64], roots[128];
+    cplx xbuf[kXbufSlots];
+    W64 w[64];
+    LaneRoots r[64];
+    WaveR() {
+        make_twiddles_1024(T1, T2);
+        make_lane_roots_1024(roots);
+        for (int l = 0; l < 64; l++) {
+            w[l] = W64{T2[1 * 8 + (l & 7)]};
+            r[l] = LaneRoots{roots[2 * l], roots[2 * l + 1]};
+        }
+    }
+    void fwd(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) fwdr_seg1(l, z[l], xbuf, r[l]);
+        for (int l = 0; l < 64; l++) fwd_seg2_ld(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) fwdr_seg2_st(l, z[l], xbuf, w[l]);
+        for (int l = 0; l < 64; l++) fwd_seg3(l, z[l], xbuf);
+    }
+    void inv(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) invr_seg1(l, z[l], xbuf, w[l]);
+        for (int l = 0; l < 64; l++) inv_seg2_ld(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) inv_seg2_st(l, z[l], xbuf);
+        for (int l = 0; l < 64; l++) invr_seg3(l, z[l], xbuf, r[l]);
+    }
+};
+// host model of wave_transpose_hi3: register index (bits 2,1,0) <-> lane bits (5,4,3)
+void lanes_transpose_hi3(cplx (*z)[8]) {
+    static cplx t[64][8];
+    for (int l = 0; l < 64; l++)
+        for (int r = 0; r < 8; r++) t[(l & 7) | (r << 3)][l >> 3] = z[l][r];
+    memcpy(z, t, sizeof(t));
+}
+struct WaveQ {  // third-generation ring kernel: as WaveR, first transpose in registers
+    WaveR base;
+    void fwd(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) fwdq_seg1(z[l], base.r[l]);
+        lanes_transpose_hi3(z);
+        for (int l = 0; l < 64; l++) fwdr_seg2_st(l, z[l], base.xbuf, base.w[l]);
+        for (int l = 0; l < 64; l++) fwd_seg3(l, z[l], base.xbuf);
+    }
+    void inv(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) invr_seg1(l, z[l], base.xbuf, base.w[l]);
+        for (int l = 0; l < 64; l++) {
+            inv_seg2_ld(l, z[l], base.xbuf);
+            dft8<-1>(z[l]);
+        }
+        lanes_transpose_hi3(z);
+        for (int l = 0; l < 64; l++) invq_seg3(z[l], base.r[l]);
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -205,6 +256,58 @@ double emu_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *o
     for (int l = 0; l < 64; l++) acc_update16(l, acc.data(), slo[l], shi[l]);
     memcpy(out, acc.data(), sizeof(int32_t) * 1024);
     return dmax;
+}
+}
+
+// variant "r" (computed pass-1 twiddles): same spectra as the table variant up to rounding, and exact products with margin.
+// Returns the worst distance of an inverse-transform output from an integer; *dmax = largest spectrum difference to the table variant.
+template <class WV>
+static double variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
+    Wave w;
+    WV wr;
+    std::vector<double> spec(2 * 512 * 2);
+    emu_transform_key_polys(b, 1, spec.data());   // key transformed by the table variant (as sk_key_transform_kernel does)
+    const cplx *B = reinterpret_cast<const cplx *>(spec.data());
+    static cplx z[64][8], z2[64][8], slo[64][8], shi[64][8];
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) z2[l][m] = z[l][m] = cplx{(double)small[l + 64 * m], (double)small[l + 64 * m + 512]};
+    wr.fwd(z);
+    w.fwd(z2);
+    double dmax = 0;
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) {
+            double d = __builtin_fabs(z[l][m].re - z2[l][m].re) + __builtin_fabs(z[l][m].im - z2[l][m].im);
+            if (d > dmax) dmax = d;
+        }
+    *dmax_out = dmax;
+    memset(slo, 0, sizeof(slo));
+    memset(shi, 0, sizeof(shi));
+    for (int l = 0; l < 64; l++) {
+        mac8(l, slo[l], z[l], B);
+        mac8(l, shi[l], z[l], B + 512);
+    }
+    wr.inv(slo);
+    wr.inv(shi);
+    double worst = 0;
+    std::vector<int32_t> acc(1024, 0);
+    for (int l = 0; l < 64; l++) {
+        for (int m = 0; m < 8; m++)
+            for (double v : {slo[l][m].re, slo[l][m].im, shi[l][m].re, shi[l][m].im}) {
+                double d = v - __builtin_rint(v);
+                if (d < 0) d = -d;
+                if (d > worst) worst = d;
+            }
+        acc_update16(l, acc.data(), slo[l], shi[l]);
+    }
+    memcpy(out, acc.data(), sizeof(int32_t) * 1024);
+    return worst;
+}
+extern "C" {
+double emu_roots_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
+    return variant_crosscheck<WaveR>(small, b, out, dmax_out);
+}
+double emu_regtranspose_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
+    return variant_crosscheck<WaveQ>(small, b, out, dmax_out);
 }
 }
 

@@ -102,6 +102,27 @@ def test_swizzled_variant_matches_padded(E, O):
     assert np.array_equal(ref, got) and d < 1e-9
 
 
+@pytest.mark.parametrize("fn", ["emu_roots_variant_crosscheck", "emu_regtranspose_variant_crosscheck"])
+@pytest.mark.parametrize("case", ["random", "adversarial"])
+def test_roots_variant_exact_with_margin(E, O, case, fn):
+    # second-generation ring kernel: pass-1 twiddles rebuilt from two per-lane roots (b * s^k0) instead of the T1 table.  The
+    # products must stay exact with a wide margin, on random digits and on the worst case of the SK-80 shape (|digit| = 512,
+    # every key word at +-2^31) where the limb sums are largest.
+    # (second variant: the same with the first transpose modelled as the in-register lane exchange of the third-generation kernel)
+    getattr(E, fn).restype = C.c_double
+    rng = np.random.default_rng(18)
+    if case == "random":
+        a = rng.integers(-512, 512, 1024).astype(np.int32); b = rng.integers(-2**31, 2**31, 1024).astype(np.int32)
+    else:
+        a = (rng.integers(0, 2, 1024) * 1023 - 512).astype(np.int32); b = np.where(rng.integers(0, 2, 1024) == 1, 2**31 - 1, -2**31).astype(np.int32)
+    ref, got = np.zeros(1024, np.int32), np.zeros(1024, np.int32)
+    O.lib().oracle_polymul_schoolbook32(O.p32(a), O.p32(b), 1024, O.p32(ref))
+    dmax = C.c_double(0)
+    margin = getattr(E, fn)(O.p32(a), O.p32(b), O.p32(got), C.byref(dmax))
+    assert np.array_equal(ref, got)
+    assert margin < 1e-4 and dmax.value < 1e-8, (margin, dmax.value)
+
+
 def test_mk_cmux_and_extract_bit_exact(E, O):
     # Torus64 3-gen CMux through the lane code (four 16-bit limbs, hi-word digits) vs the MK oracle's schoolbook path
     for name, n, parties in (("MK2", 6, 2), ("MK4", 3, 2)):

@@ -35,7 +35,9 @@ __global__ __launch_bounds__(512) void dma_stream(const uint4 *__restrict__ src,
     int slot = 0;
     size_t issued = 0;
     auto issue = [&]() {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(p + issued * 512), "s"(base + (unsigned)slot * 8192u) : "memory");
+        const uint4 *g = p + issued * 512;
+        const unsigned off = __builtin_amdgcn_readfirstlane(base + (unsigned)slot * 8192u);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(off) : "memory", "m0");
         issued++;
         slot = slot + 1 == SLOTS ? 0 : slot + 1;
     };

@@ -16,7 +16,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 p = thfhe.make_params("SK-128")
 K = keygen.SecretKeySet(p, seed=1)
 ck = thfhe.CloudKey(p, K.bk, K.ksk)
-ck.set_coop_threshold(0)
+COOP = os.environ.get("STAMP_KERNEL", "ring") == "coop"
+ck.set_coop_threshold(1 << 20 if COOP else 0)
 rng = np.random.default_rng(0)
 xa, xb = K.encrypt(rng.integers(0, 2, B), 1), K.encrypt(rng.integers(0, 2, B), 2)
 da, db, do = ck.device_records(B), ck.device_records(B), ck.device_records(B)
@@ -25,16 +26,19 @@ for _ in range(2):
     ck.gates_dev(thfhe.NAND, da, db, None, do, B); ck.sync()
 t = ck.last_timings()
 L = thfhe.lib()
-nwg = min((B + 7) // 8, 2048)
+nwg = min(B if COOP else (B + 7) // 8, 2048)
 buf = np.zeros(nwg * 8 * 8, np.uint64)
 L.thfhe_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.thfhe_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
-st = buf.reshape(nwg, 8, 8)[:, :, :4].astype(np.float64) / p.n   # cycles per CMux
-names = ["rotate+decompose+fwd FFT (6 rows)", "chunk barriers (30)", "key reads + MAC (24 chunks)", "4 inverse FFT + acc update"]
+NS = 6 if COOP else 4
+st = buf.reshape(nwg, 8, 8)[:, :, :NS].astype(np.float64) / p.n   # cycles per CMux
+names = (["F: rotate+decompose+fwd FFT+publish", "wait at barrier 1", "M: spectra reads + MAC", "hand-off / prefetch issue / I: inverse+atomics",
+          "wait at barrier 2", "wait at barrier 3"] if COOP else
+         ["rotate+decompose+fwd FFT (6 rows)", "chunk barriers (30)", "key reads + MAC (24 chunks)", "4 inverse FFT + acc update"])
 print(f"batch {B}: blind rotate {t['blind_rotate_ms']:.3f} ms; s_memtime ticks per CMux per wave (mean over {nwg} workgroups x 8 waves; 100 MHz ticks x clock ratio):")
 tot = st.sum(axis=2).mean()
 for q, nm in enumerate(names):
     print(f"  {nm:40s} {st[:, :, q].mean():10.1f}  ({100 * st[:, :, q].mean() / tot:5.1f} %)   per-wave min {st[:, :, q].min():9.1f} max {st[:, :, q].max():9.1f}")
 print(f"  total {tot:.1f}")
 for w in range(8):
-    print(f"  wave {w}: " + "  ".join(f"{st[:, w, q].mean():9.1f}" for q in range(4)))
+    print(f"  wave {w}: " + "  ".join(f"{st[:, w, q].mean():9.1f}" for q in range(NS)))

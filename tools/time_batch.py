@@ -16,5 +16,7 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
     for rep in range(3):
         ck.gates_dev(thfhe.NAND, da, db, None, do, B); ck.sync()
         t = ck.last_timings()
-    print(f"batch {B}: blind_rotate {t['blind_rotate_ms']:.3f} ms keyswitch {t['keyswitch_ms']:.3f} ms total {t['total_ms']:.3f} ms -> {B/t['total_ms']*1e3:.0f} gates/s", flush=True)
+    import hashlib
+    digest = hashlib.sha256(do.download((B, p.n + 1)).tobytes()).hexdigest()[:16]   # same inputs -> same bytes, whatever kernel variant ran
+    print(f"batch {B} [out sha {digest}]: blind_rotate {t['blind_rotate_ms']:.3f} ms keyswitch {t['keyswitch_ms']:.3f} ms total {t['total_ms']:.3f} ms -> {B/t['total_ms']*1e3:.0f} gates/s", flush=True)
     for d in (da, db, do): d.free()

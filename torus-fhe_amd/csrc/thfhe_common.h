@@ -83,6 +83,77 @@ __device__ __forceinline__ void wave_fft_inv_s(int lane, cplx (&z)[8], cplx *xb,
     wave_sync();
     invs_seg3(lane, z, xb, T1);
 }
+// variant "r": padded buffer, pass-1 twiddles from per-lane roots (thfhe_lane.h)
+__device__ __forceinline__ void wave_fft_fwd_r(int lane, cplx (&z)[8], cplx *xb, const LaneRoots &r, const W64 &w) {
+    wave_sync();
+    fwdr_seg1(lane, z, xb, r);
+    wave_sync();
+    fwd_seg2_ld(lane, z, xb);
+    fwdr_seg2_st(lane, z, xb, w);
+    wave_sync();
+    fwd_seg3(lane, z, xb);
+}
+__device__ __forceinline__ void wave_fft_inv_r(int lane, cplx (&z)[8], cplx *xb, const LaneRoots &r, const W64 &w) {
+    wave_sync();
+    invr_seg1(lane, z, xb, w);
+    wave_sync();
+    inv_seg2_ld(lane, z, xb);
+    inv_seg2_st(lane, z, xb);
+    wave_sync();
+    invr_seg3(lane, z, xb, r);
+}
+// variant "q": first transpose in registers.  Exchange of the register index (bits 2,1,0) with lane bits (5,4,3):
+//   stage A  z[r] (r < 4) of the upper half-wave <-> z[r + 4] of the lower half-wave      v_permlane32_swap
+//   stage B  z[r] (bit 1 clear) of the odd 16-lane rows <-> z[r + 2] of the even rows      v_permlane16_swap
+//   stage C  lanes with bit 3 clear take z[r] (r even) of lane ^ 8 into z[r + 1], lanes with bit 3 set take z[r + 1] into z[r]
+//            (row_ror:8 DPP moves, bank masks 0x3 / 0xC)
+// The exchange is its own inverse.
+__device__ __forceinline__ void wave_transpose_hi3(cplx (&z)[8]) {
+    uint32_t w[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) __builtin_memcpy(w[r], &z[r], 16);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            auto q = __builtin_amdgcn_permlane32_swap(w[r][d], w[r + 4][d], false, false);
+            w[r][d] = q[0];
+            w[r + 4][d] = q[1];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (r & 2) continue;
+            auto q = __builtin_amdgcn_permlane16_swap(w[r][d], w[r + 2][d], false, false);
+            w[r][d] = q[0];
+            w[r + 2][d] = q[1];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            const uint32_t a = w[r][d], b = w[r + 1][d];
+            w[r + 1][d] = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xF, 0x3, false);
+            w[r][d] = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xF, 0xC, false);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) __builtin_memcpy(&z[r], w[r], 16);
+}
+__device__ __forceinline__ void wave_fft_fwd_q(int lane, cplx (&z)[8], cplx *xb, const LaneRoots &r, const W64 &w) {
+    fwdq_seg1(z, r);
+    wave_transpose_hi3(z);
+    wave_sync();
+    fwdr_seg2_st(lane, z, xb, w);
+    wave_sync();
+    fwd_seg3(lane, z, xb);
+}
+__device__ __forceinline__ void wave_fft_inv_q(int lane, cplx (&z)[8], cplx *xb, const LaneRoots &r, const W64 &w) {
+    wave_sync();
+    invr_seg1(lane, z, xb, w);
+    wave_sync();
+    inv_seg2_ld(lane, z, xb);
+    dft8<-1>(z);
+    wave_transpose_hi3(z);
+    invq_seg3(z, r);
+}
 // N = 2048 halves: twisted 512-point transforms (thfhe_lane.h, "N = 2048" section); T1t = the table of twist T
 template <int T>
 __device__ __forceinline__ void wave_fft_fwd_t(int lane, cplx (&z)[8], cplx *xb, const cplx *T1t, const W64 &w) {

@@ -233,6 +233,101 @@ THFHE_FN void invs_seg3(int lane, cplx (&z)[8], const cplx *xbuf, const cplx *T1
     for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
 }
 
+// ---- variant "r" (second-generation LDS-ring kernel): padded 576-slot buffer (three LDS address registers per wave instead of
+// the 25 the XOR maps need) and pass-1 twiddles rebuilt from two per-lane roots instead of read from the 8 KiB T1 table:
+//     T1[k0][lane] = zeta^(lane (4 k0 + 1)) = b * s^k0,    b = zeta^lane,  s = zeta^(4 lane)
+// (one square and seven products per transform, two interleaved chains of depth 4; the table reads were a dependent LDS round trip
+// in front of every transpose store, the products are FP64 work the SIMD has room for).  Same spectra order as the other variants.
+struct LaneRoots {
+    cplx b, s;
+};
+THFHE_FN void fwdr_seg1(int lane, cplx (&z)[8], cplx *xbuf, const LaneRoots &r) {
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+    dft8<+1>(z);
+    const cplx s2 = cmul(r.s, r.s);
+    cplx e = r.b, o = cmul(r.b, r.s);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += 2) {
+        xbuf[xs_a(k0, lane)] = cmul(z[k0], e);
+        xbuf[xs_a(k0 + 1, lane)] = cmul(z[k0 + 1], o);
+        if (k0 < 6) {
+            e = cmul(e, s2);
+            o = cmul(o, s2);
+        }
+    }
+}
+THFHE_FN void fwdr_seg2_st(int lane, cplx (&z)[8], cplx *xbuf, const W64 &w) {
+    dft8<+1>(z);
+    cplx p[8];
+    w64_powers(w, p);
+    xbuf[xs_c(0, lane)] = z[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; k1++) xbuf[xs_c(k1, lane)] = cmul(z[k1], p[k1]);
+}
+THFHE_FN void invr_seg1(int lane, cplx (&z)[8], cplx *xbuf, const W64 &w) {
+    dft8<-1>(z);
+    cplx p[8];
+    w64_powers(w, p);
+    xbuf[xs_d(0, lane)] = z[0];
+#pragma unroll
+    for (int j0 = 1; j0 < 8; j0++) xbuf[xs_d(j0, lane)] = cmul_conj(z[j0], p[j0]);
+}
+THFHE_FN void invr_seg3(int lane, cplx (&z)[8], const cplx *xbuf, const LaneRoots &r) {
+    const cplx s2 = cmul(r.s, r.s);
+    cplx e = r.b, o = cmul(r.b, r.s);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += 2) {
+        z[k0] = cmul_conj(xbuf[xs_a(k0, lane)], e);
+        z[k0 + 1] = cmul_conj(xbuf[xs_a(k0 + 1, lane)], o);
+        if (k0 < 6) {
+            e = cmul(e, s2);
+            o = cmul(o, s2);
+        }
+    }
+    dft8<-1>(z);
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+}
+
+// ---- variant "q": as "r", but the FIRST transpose (register index <-> lane bits 3..5) never touches the LDS: the wave exchanges
+// registers between its lanes with v_permlane32_swap (lane bit 5), v_permlane16_swap (bit 4) and a row_ror:8 DPP move (bit 3) --
+// 80 32-bit VALU instructions per transpose in place of 8 ds_write_b128 + 8 ds_read_b128 (136 cycles of the CU's one LDS pipe, the
+// busiest unit of the first-generation kernel).  The lane functions below are the per-lane halves; the exchange itself is
+// wave_transpose_hi3 (thfhe_common.h on the device, lanes_transpose_hi3 in the emulator).
+THFHE_FN void fwdq_seg1(cplx (&z)[8], const LaneRoots &r) {
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+    dft8<+1>(z);
+    const cplx s2 = cmul(r.s, r.s);
+    cplx e = r.b, o = cmul(r.b, r.s);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += 2) {
+        z[k0] = cmul(z[k0], e);
+        z[k0 + 1] = cmul(z[k0 + 1], o);
+        if (k0 < 6) {
+            e = cmul(e, s2);
+            o = cmul(o, s2);
+        }
+    }
+}
+THFHE_FN void invq_seg3(cplx (&z)[8], const LaneRoots &r) {
+    const cplx s2 = cmul(r.s, r.s);
+    cplx e = r.b, o = cmul(r.b, r.s);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += 2) {
+        z[k0] = cmul_conj(z[k0], e);
+        z[k0 + 1] = cmul_conj(z[k0 + 1], o);
+        if (k0 < 6) {
+            e = cmul(e, s2);
+            o = cmul(o, s2);
+        }
+    }
+    dft8<-1>(z);
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+}
+
 // ---- integer helpers ---------------------------------------------------------------------------------
 // coefficient q of X^a * p - p for p in LDS, a in [0, 2N)          (mul_by_monomial, J/rlwe.jl:130-131)
 THFHE_FN uint32_t rot_minus_self32(const int32_t *p, int q, int a2n, int N) {
@@ -589,6 +684,15 @@ inline void make_twiddles_1024(cplx *T1 /*512*/, cplx *T2 /*64*/) {
             long double ang = 2.0L * PI * (long double)(j0 * k1) / 64.0L;
             T2[k1 * 8 + j0] = cplx{(double)cosl(ang), (double)sinl(ang)};
         }
+}
+// per-lane roots of variant "r": roots[2*lane] = exp(i pi lane / 1024), roots[2*lane + 1] = exp(i pi 4 lane / 1024)
+inline void make_lane_roots_1024(cplx *roots /*128*/) {
+    const long double PI = 3.14159265358979323846264338327950288L;
+    for (int lane = 0; lane < 64; lane++) {
+        long double a = PI * (long double)lane / 1024.0L, b = PI * (long double)(4 * lane) / 1024.0L;
+        roots[2 * lane] = cplx{(double)cosl(a), (double)sinl(a)};
+        roots[2 * lane + 1] = cplx{(double)cosl(b), (double)sinl(b)};
+    }
 }
 // N = 2048: T1_T[k0*64 + lane] = exp(i pi lane (8 k0 + T) / 2048) for the two twists T = 1 (even outputs) and T = 5 (odd outputs)
 inline void make_twiddles_2048(cplx *T1a /*512, T = 1*/, cplx *T1b /*512, T = 5*/) {

@@ -137,32 +137,44 @@ struct BRArgs {
 };
 
 // ------------------------------------------------------------------------------------------------------
-// blind rotate + extract, throughput kernel ("LDS ring").
+// blind rotate + extract, throughput kernel ("LDS ring", second generation).
 //
 // One 512-thread workgroup = 8 wavefronts = 8 jobs, one workgroup per CU, all 160 KiB of LDS:
-//     T1 twiddles 8 KiB | 8 x (accumulator 8 KiB + transpose buffer 8 KiB) | key ring 3 x 8 KiB        = 163 840 B
-// The eight waves walk the key index i, the digit rows and the four (column, limb) chunks of a row in lock step.
-// A chunk is 8 KiB of key spectrum = 8 slices of 1 KiB; wave w brings slice w into the ring with ONE
-// global_load_lds_dwordx4 (LDS-DMA, no registers), so the whole key crosses the CU's vector-memory path once per
-// workgroup instead of once per wave (the first-generation kernel -- one wave per job with its own key loads, git history --
-// was bound by exactly that path: profiles/r01_summary.md).
-// Hand-off of chunk q: every wave waits for its own slice (s_waitcnt vmcnt(N), N = younger DMAs in flight), then
-// s_barrier -- after it the chunk is complete AND everybody has finished reading chunk q-1, whose slot is refilled
-// at once with chunk q+2.  One extra barrier after a row's last chunk frees that slot before the next transform, so
-// three chunks are in flight under every forward transform.  Per row: 5 barriers, 4 DMA issues per wave.
-// A wave whose mod-switched mask word is 0 (J/bootstrap.jl:40) or that has no job still streams and synchronises.
+//     8 x (accumulator int32[2][1024] 8 KiB + transpose buffer 9 KiB) | key ring 3 x 8 KiB                  = 163 840 B
+// Each wave owns one job; its accumulator never leaves LDS during the n CMuxes.  The eight waves walk the key index i, the digit
+// rows and the four (column, limb) chunks of a row in lock step.  A chunk is 8 KiB of key spectrum = 8 slices of 1 KiB; wave w brings
+// slice w into the ring with ONE global_load_lds_dwordx4 (LDS-DMA, no registers), so the whole key crosses the CU's vector-memory
+// path once per workgroup instead of once per wave.  Hand-off of chunk q: every wave waits for its own slice (s_waitcnt vmcnt(N),
+// N = younger DMAs in flight), then s_barrier -- after it the chunk is complete AND everybody has finished reading chunk q-1, whose
+// slot is refilled at once with chunk q+2.  Per row: 5 barriers, 4 DMA issues per wave.  A wave whose mod-switched mask word is 0
+// (J/bootstrap.jl:40) or that has no job still streams and synchronises.
+//
+// What the second generation changed comes from an in-kernel cycle trace and the PMC counters of the first (tools/ring_stamps.py,
+// profiles/r02_ring_generations.md): with two waves per SIMD that kernel was bound by exposed LDS round trips and by the LDS
+// instruction pipe (69 % busy, bursts in lock step), with the VALU 55 % busy.  So:
+//   * the FIRST transpose of every transform (register index <-> lane bits 3..5) stays in registers: v_permlane32_swap,
+//     v_permlane16_swap and row_ror:8 DPP moves (wave_transpose_hi3) instead of 8 ds_write_b128 + 8 ds_read_b128;
+//   * pass-1 twiddles are rebuilt from two per-lane roots (thfhe_lane.h, variant "q") instead of read from a T1 table in LDS: the
+//     table reads sat between the butterflies and the transpose of every transform;
+//   * the second transpose uses the padded 576-slot buffer (the 8 KiB of the T1 table pay for the padding): its slot maps are
+//     base + immediate, 2 LDS address registers per wave instead of 16 for the XOR-swizzled maps;
+//   * the multiply-accumulate is software-pipelined over half chunks: the four ring reads of one half are in flight under the
+//     16 FMAs of the half before (the first generation read one slice, used it, read the next: 8 serial round trips per chunk),
+//     and S += z * b is four FMAs (the mul + fma + add form cost 384 more FP64 instructions per CMux);
+//   * the rotated differences X^a acc - acc are re-read from the accumulator for every digit level instead of living in 16
+//     registers across transform and multiply (the compiler had spilled them to scratch).
+// LDS pipe instructions per launch 1.74e9 -> 1.38e9, LDS pipe busy 69 % -> 46 %, VALU busy 55 % -> 75 %, 34.8 -> 33.3 ms per 4096 gates.
 // ------------------------------------------------------------------------------------------------------
-template <int L, int V = 0>
+template <int L, int V = 1>
 __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) {
-    __shared__ cplx sT1[512];
     __shared__ int32_t sAcc[8][2048];
-    __shared__ cplx sX[8][512];
+    __shared__ cplx sX[8][kXbufSlots];
     __shared__ cplx sRing[3][512];
     constexpr int ROWS = 2 * L;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    sT1[threadIdx.x] = a.tw[threadIdx.x];
     const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
+    const LaneRoots roots{a.tw[576 + 2 * lane], a.tw[576 + 2 * lane + 1]};
     const long job = (long)blockIdx.x * 8 + wave;
     const bool has_job = job < a.jobs;
     int32_t *acc = sAcc[wave];
@@ -172,21 +184,20 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
     const uint32_t offset = decomp_offset32(L, Bgbit);
     if (has_job) acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
 
-    // key stream: chunk q lives at a.bk + q*512 (complex); this wave's slice is +wave*64, this lane's element +lane
     const long total_chunks = (long)a.n * ROWS * 4;
-    const cplx *gsrc = a.bk + wave * 64 + lane;     // advances by 512 complex per issued chunk
+    const cplx *gsrc = a.bk + wave * 64 + lane;
     long q_issue = 0;
     int slot_issue = 0;
     const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sRing[0][0] + (uint32_t)wave * 1024u;
     auto issue = [&]() {
         ring_dma(gsrc, ring_base + (uint32_t)slot_issue * 8192u);
-        if (q_issue + 1 < total_chunks) {  // past the end the last chunk is re-requested: keeps the vmcnt pattern uniform
+        if (q_issue + 1 < total_chunks) {
             gsrc += 512;
             q_issue++;
         }
         slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
     };
-    __syncthreads();  // twiddles + accumulators visible; nothing in flight yet
+    __syncthreads();
     issue();
     issue();
     issue();
@@ -194,8 +205,8 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
     STAMP_DECL;
 
     for (int i = 0; i < a.n; i++) {
-        const int ai = bara[i];                      // wave-uniform
-        const bool active = has_job && ai != 0;      // J/bootstrap.jl:40
+        const int ai = bara[i];
+        const bool active = has_job && ai != 0;
         const int a2n = ai & 2047;
         cplx S[2][2][8];
 #pragma unroll
@@ -204,133 +215,142 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
             for (int h = 0; h < 2; h++)
 #pragma unroll
                 for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
-        uint32_t t[16];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             cplx z[8];
             if (active) {
-                if (r % L == 0) load_rotated16(lane, acc + (r / L) * 1024, a2n, offset, t);
+                // the rotated differences are re-read from the accumulator for every level: 32 LDS dwords per row cost less than keeping
+                // 16 registers alive across the transform and the multiply (the compiler spilled them to scratch: a far longer round trip)
+                uint32_t t[16];
+                int a2n_r = a2n;
+                asm volatile("" : "+s"(a2n_r));  // opaque per row: the 16 rotated LDS addresses are recomputed (3 integer ops each), not kept alive
+                load_rotated16(lane, acc + (r / L) * 1024, a2n_r, offset, t);
                 digits_to_z(t, (r % L) + 1, Bgbit, z);
-                wave_fft_fwd_s(lane, z, xb, sT1, w64);
+                if (V & 1) wave_fft_fwd_q(lane, z, xb, roots, w64); else wave_fft_fwd_r(lane, z, xb, roots, w64);
             }
-            STAMP(0);  // rotate + decompose + forward transform
-            if (V == 1) {
-                // software-pipelined multiply: the key reads of a half chunk (4 slices) are in flight under the 16 FMAs of the half
-                // chunk before it, so the LDS latency of the ring reads hides behind this wave's own FP64 work instead of stalling it
-                cplx bA[4], bB[4];
+            STAMP(0);
+            cplx bA[4], bB[4];
 #pragma unroll
-                for (int c4 = 0; c4 < 4; c4++) {
-                    if (c4 == 0) ring_barrier<2>(); else ring_barrier<1>();
-                    STAMP(1);
-                    if (c4 > 0) issue();
-                    const cplx *B = &sRing[slot_use][0];
-                    if (active) {
-#pragma unroll
-                        for (int m = 0; m < 4; m++) bA[m] = B[m * 64 + lane];
-                        if (c4 > 0) {
-#pragma unroll
-                            for (int m = 0; m < 4; m++) cfma(S[(c4 - 1) >> 1][(c4 - 1) & 1][4 + m], z[4 + m], bB[m]);
-                        }
-#pragma unroll
-                        for (int m = 0; m < 4; m++) bB[m] = B[(4 + m) * 64 + lane];
-#pragma unroll
-                        for (int m = 0; m < 4; m++) cfma(S[c4 >> 1][c4 & 1][m], z[m], bA[m]);
-                    }
-                    slot_use = slot_use == 2 ? 0 : slot_use + 1;
-                    STAMP(2);
-                }
-                ring_barrier<2>();
-                issue();
+            for (int c4 = 0; c4 < 4; c4++) {
+                if (c4 == 0) ring_barrier<2>(); else ring_barrier<1>();
                 STAMP(1);
+                if (c4 > 0) issue();
+                const cplx *B = &sRing[slot_use][0];
                 if (active) {
 #pragma unroll
-                    for (int m = 0; m < 4; m++) cfma(S[1][1][4 + m], z[4 + m], bB[m]);
-                }
-                STAMP(2);
-            } else {
+                    for (int m = 0; m < 4; m++) bA[m] = B[m * 64 + lane];
+                    if (c4 > 0) {
 #pragma unroll
-                for (int c4 = 0; c4 < 4; c4++) {
-                    // publish chunk: own slice landed (c4 == 0: two younger DMAs in flight, else one), then everybody
-                    if (c4 == 0) ring_barrier<2>(); else ring_barrier<1>();
-                    STAMP(1);  // waiting at the chunk barriers
-                    if (c4 > 0) issue();  // the slot of the chunk consumed before this barrier is free
-                    if (active) {
-                        if (V == 2) mac8<1>(lane, S[c4 >> 1][c4 & 1], z, &sRing[slot_use][0]);
-                        else mac8_lean(lane, S[c4 >> 1][c4 & 1], z, &sRing[slot_use][0]);
+                        for (int m = 0; m < 4; m++) cfma(S[(c4 - 1) >> 1][(c4 - 1) & 1][4 + m], z[4 + m], bB[m]);
                     }
-                    slot_use = slot_use == 2 ? 0 : slot_use + 1;
-                    STAMP(2);  // key reads + multiply-accumulate
+#pragma unroll
+                    for (int m = 0; m < 4; m++) bB[m] = B[(4 + m) * 64 + lane];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) cfma(S[c4 >> 1][c4 & 1][m], z[m], bA[m]);
                 }
-                ring_barrier<2>();  // the row's last chunk is consumed by all: refill its slot before the next transform
-                issue();
-                STAMP(1);
+                slot_use = slot_use == 2 ? 0 : slot_use + 1;
+                STAMP(2);
             }
+            ring_barrier<2>();  // the row's last chunk is read by all (its second half sits in bB): refill its slot before the next transform
+            issue();
+            STAMP(1);
+            if (active) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) cfma(S[1][1][4 + m], z[4 + m], bB[m]);
+            }
+            STAMP(2);
         }
         if (active) {
-            wave_sync();  // every rotated read of acc precedes the updates below
+            wave_sync();
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                wave_fft_inv_s(lane, S[c][0], xb, sT1, w64);
-                wave_fft_inv_s(lane, S[c][1], xb, sT1, w64);
+                if (V & 1) {
+                    wave_fft_inv_q(lane, S[c][0], xb, roots, w64);
+                    wave_fft_inv_q(lane, S[c][1], xb, roots, w64);
+                } else {
+                    wave_fft_inv_r(lane, S[c][0], xb, roots, w64);
+                    wave_fft_inv_r(lane, S[c][1], xb, roots, w64);
+                }
                 acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
             }
             wave_sync();
         }
-        STAMP(3);  // inverse transforms + accumulator update
+        STAMP(3);
     }
     STAMP_FLUSH(blockIdx.x, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (has_job) extract16(lane, acc, acc + 1024, a.out + job * 1025);
 }
 
 // ------------------------------------------------------------------------------------------------------
-// blind rotate + extract, latency kernel ("cooperative"): one 512-thread workgroup = ONE job.  For the small batches the
-// reference's gate-at-a-time callers produce (boots* shims, ripple-carry circuits) the ring kernel leaves 7/8 of a CU idle;
-// here the work of one CMux is spread over the eight waves:
-//   phase 1  waves 0 .. 2l-1: wave r rotates / decomposes / transforms digit row r and publishes its spectrum in LDS;
-//            every wave has already requested the key chunks of its phase-2 role (l rows x 8 loads of 16 B per lane);
-//   phase 2  wave w = (column c, limb h, half): S = sum over its half of the rows of spectrum_r * key(r, c, h); inverse
-//            transform of this PARTIAL sum (the inverse is linear and every partial sum is an exact integer polynomial);
-//            round(S) << 16h is added into accumulator polynomial c with 32-bit LDS atomics (integer adds commute).
-// Two workgroup barriers per CMux; each key byte is fetched once per CU.  LDS: T1 8 + acc 8 + spectra 2l x 8 + 8 x 8 KiB.
+// blind rotate + extract, latency kernel ("cooperative", second generation): one 512-thread workgroup = ONE job.  For the small
+// batches the reference's gate-at-a-time callers produce (boots* shims, ripple-carry circuits: 855 of the 1 033 levels of the KNN
+// decision hold 1-3 gates) the ring kernel leaves 7/8 of a CU idle; here the work of one CMux is spread over the eight waves and
+// the n CMuxes are a dependent chain, so what counts is the length of one step's critical path:
+//   F  waves 0 .. 2l-1: wave r rotates / decomposes / transforms digit row r and publishes its spectrum in LDS;       barrier
+//   M  wave w = (column c, limb h, half): S = sum over its half of the rows of spectrum_r * key(r, c, h) (key chunks in registers);
+//      the waves of half 1 hand their partial sums to their partners through LDS;                                     barrier
+//   I  waves 0-3 (one per SIMD) add the partner's partial sum, inverse-transform, and add round(S) << 16h into accumulator
+//      polynomial c with 32-bit LDS atomics (two limbs per polynomial; integer adds commute -> bit-exact);            barrier
+// The key stream is what the first generation tripped over: it requested the 24 chunks of a step (192 KiB per workgroup at l = 3)
+// at the top of the step, in front of the forward transforms -- 192 wave-loads queue up on the CU's one vector-memory path
+// (64 B/clk: ~3 k cycles) and a wave cannot start its transform before its own loads have been accepted.  A microbenchmark
+// (tools/probes/fetch_probe.hip, profiles/r02_fetch_probe.md) shows one CU can pull the 121 MB key at 95-113 GB/s when loads are
+// spread out, 2.4x what that kernel reached.  Here the chunks of step i+1 are requested during step i, once the registers that
+// held step i's chunks are dead: the idle waves of half 1 right after the hand-off, the transforming waves one row's worth at a
+// time between the stages of their inverse transform (compiler fences pin the places) -- nobody's transform waits on the queue.
+// Transforms are variant "r" (padded buffer, pass-1 twiddles from per-lane roots): LDS = acc 8 + spectra 2l x 8 + 8 x 9 KiB.
 // ------------------------------------------------------------------------------------------------------
-template <int L>
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void pin() { asm volatile("" ::: "memory"); }  // memory operations do not move across this point
+
+template <int L, int PACE = 1>
 __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) {
     constexpr int ROWS = 2 * L;
-    __shared__ cplx sT1[512];
     __shared__ int32_t sAcc[2048];
     __shared__ cplx sSpec[ROWS][512];
-    __shared__ cplx sX[8][512];
+    __shared__ cplx sX[8][kXbufSlots];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    sT1[threadIdx.x] = a.tw[threadIdx.x];
     const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
+    const LaneRoots roots{a.tw[576 + 2 * lane], a.tw[576 + 2 * lane + 1]};
     const long job = blockIdx.x;
     const int32_t *bara = a.bara + job * a.n_pad;
     const int Bgbit = a.Bgbit;
     const uint32_t offset = decomp_offset32(L, Bgbit);
     if (wave == 0) acc_init16(lane, sAcc, sAcc + 1024, a.barb[job], a.mu);
-    __syncthreads();
-    const int c = (wave >> 2) & 1, h = (wave >> 1) & 1, r0 = (wave & 1) * L;  // phase-2 role: rows r0 .. r0+L-1
+    const int c = (wave >> 1) & 1, h = wave & 1, half = wave >> 2, r0 = half * L;  // role in M: rows r0 .. r0+L-1 of (column c, limb h)
     unsigned int *ap = reinterpret_cast<unsigned int *>(sAcc) + c * 1024;
+    cplx *xb = sX[wave];
 
-    for (int i = 0; i < a.n; i++) {
-        const int ai = bara[i];  // uniform over the workgroup
-        if (ai == 0) continue;   // J/bootstrap.jl:40
-        const int a2n = ai & 2047;
-        cplx B[L][8];
+    int i = 0;
+    while (i < a.n && bara[i] == 0) i++;   // J/bootstrap.jl:40: mask words that mod-switch to 0 are skipped (uniform over the workgroup)
+    cplx B[L][8];
+    if (i < a.n) {
 #pragma unroll
         for (int r = 0; r < L; r++) load8(lane, B[r], a.bk + bk_spec_index(i, r0 + r, c, h, ROWS));
+    }
+    wg_barrier();
+    STAMP_DECL;
+    while (i < a.n) {
+        const int a2n = bara[i] & 2047;
+        int inext = i + 1;
+        while (inext < a.n && bara[inext] == 0) inext++;
+        const int inl = inext < a.n ? inext : i;   // the last step re-requests its own chunks: unconditional loads keep B one set of registers
+        // ---- F ----
         if (wave < ROWS) {
             uint32_t t[16];
             cplx z[8];
             load_rotated16(lane, sAcc + (wave / L) * 1024, a2n, offset, t);
             digits_to_z(t, (wave % L) + 1, Bgbit, z);
-            wave_fft_fwd_s(lane, z, sX[wave], sT1, w64);
+            wave_fft_fwd_q(lane, z, xb, roots, w64);
 #pragma unroll
             for (int m = 0; m < 8; m++) sSpec[wave][m * 64 + lane] = z[m];
         }
-        __syncthreads();  // spectra published; every rotated read of the accumulator is done
+        STAMP(0);
+        wg_barrier();  // spectra published; every rotated read of the accumulator is done
+        STAMP(1);
+        // ---- M ----
         cplx S[8];
 #pragma unroll
         for (int m = 0; m < 8; m++) S[m] = cplx{0.0, 0.0};
@@ -340,16 +360,69 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
 #pragma unroll
             for (int m = 0; m < 8; m++) z[m] = sSpec[r0 + r][m * 64 + lane];
             mac8r(S, z, B[r]);
+            pin();   // one row's spectrum in registers at a time (hoisting all 2l x 8 reads costs more registers than there are)
         }
-        wave_fft_inv_s(lane, S, sX[wave], sT1, w64);
+        STAMP(2);
+        if (half == 1) {
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            const int q = lane + 64 * m;
-            atomicAdd(ap + q, round_lo32(S[m].re) << (16 * h));
-            atomicAdd(ap + q + 512, round_lo32(S[m].im) << (16 * h));
+            for (int m = 0; m < 8; m++) xb[m * 64 + lane] = S[m];   // hand-off to wave - 4 (this wave's transpose buffer is idle)
+            pin();
+            STAMP(3);
+            wg_barrier();
+            STAMP(4);
+            // nothing else to do until the next step: request all of its chunks now (AFTER the barrier: the partners' inverse
+            // transforms must not wait for these 8 l loads to be accepted by the memory pipeline)
+#pragma unroll
+            for (int r = 0; r < L; r++) {
+                const cplx *src = a.bk + bk_spec_index(inl, r0 + r, c, h, ROWS);
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    B[r][m] = src[m * 64 + lane];
+                    pin();
+                    __builtin_amdgcn_s_sleep(PACE);   // paced: these waves have the whole inverse phase; a flooded queue stalls the partners' loads
+                }
+            }
+        } else {
+            load8(lane, B[0], a.bk + bk_spec_index(inl, r0, c, h, ROWS));
+            pin();
+            STAMP(3);
+            wg_barrier();
+            STAMP(4);
+            // ---- I ----
+            const cplx *px = sX[wave + 4];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const cplx v = px[m * 64 + lane];
+                S[m].re += v.re;
+                S[m].im += v.im;
+            }
+            wave_sync();
+            invr_seg1(lane, S, xb, w64);
+            pin();
+            if (L > 1) load8(lane, B[L > 1 ? 1 : 0], a.bk + bk_spec_index(inl, r0 + 1, c, h, ROWS));
+            pin();
+            wave_sync();
+            inv_seg2_ld(lane, S, xb);
+            dft8<-1>(S);
+            pin();
+            if (L > 2) load8(lane, B[L > 2 ? 2 : 0], a.bk + bk_spec_index(inl, r0 + 2, c, h, ROWS));
+            if (L > 3) load8(lane, B[L > 3 ? 3 : 0], a.bk + bk_spec_index(inl, r0 + 3, c, h, ROWS));
+            pin();
+            wave_transpose_hi3(S);
+            invq_seg3(S, roots);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int q = lane + 64 * m;
+                atomicAdd(ap + q, round_lo32(S[m].re) << (16 * h));
+                atomicAdd(ap + q + 512, round_lo32(S[m].im) << (16 * h));
+            }
         }
-        __syncthreads();  // accumulator updated before anybody rotates it again
+        STAMP(3);
+        wg_barrier();  // accumulator updated before anybody rotates it again
+        STAMP(5);
+        i = inext;
     }
+    STAMP_FLUSH(blockIdx.x, wave);
     if (wave == 0) extract16(lane, sAcc, sAcc + 1024, a.out + job * 1025);
 }
 
@@ -622,16 +695,21 @@ template <int L>
 void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
     // small batches: cooperative latency kernel (one workgroup per gate); large ones: LDS-ring kernel (eight gates per workgroup)
     if (a.jobs <= coop_max) {
-        hipLaunchKernelGGL(sk_blind_rotate_coop_kernel<L>, dim3((unsigned)a.jobs), dim3(512), 0, s, a);
+#ifdef THFHE_VARIANTS
+        static const int pace = std::getenv("THFHE_COOP_PACE") ? std::atoi(std::getenv("THFHE_COOP_PACE")) : 1;
+        if (pace == 0) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 0>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
+        if (pace == 2) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 2>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
+        if (pace == 4) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 4>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
+#endif
+        hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 1>), dim3((unsigned)a.jobs), dim3(512), 0, s, a);
         return;
     }
     const dim3 grid((unsigned)((a.jobs + 7) / 8)), block(512);
-#ifdef THFHE_VARIANTS  // developer A/B builds only
+#ifdef THFHE_VARIANTS  // developer A/B builds only: 8 = first transpose through the LDS (variant "r")
     static const int variant = std::getenv("THFHE_RING_VARIANT") ? std::atoi(std::getenv("THFHE_RING_VARIANT")) : 0;
-    if (L == 3 && variant == 1) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 1>), grid, block, 0, s, a); return; }
-    if (L == 3 && variant == 2) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 2>), grid, block, 0, s, a); return; }
+    if (variant == 8) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 0>), grid, block, 0, s, a); return; }
 #endif
-    hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 0>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 1>), grid, block, 0, s, a);
 }
 
 // rotations (prologue + blind rotate) of `jobs` = gates * rot_per_gate jobs into c->d_u
@@ -762,8 +840,9 @@ int thfhe_ctx_create(const thfhe_params *p, const int32_t *bk_coeff, const int32
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &e : c->ev) CK(hipEventCreate(&e));
     // twiddles
-    std::vector<cplx> tw(576);
+    std::vector<cplx> tw(576 + 128);  // T1[512] T2[64] lane roots[128]
     make_twiddles_1024(tw.data(), tw.data() + 512);
+    make_lane_roots_1024(tw.data() + 576);
     CK(hipMalloc(&c->d_tw, tw.size() * sizeof(cplx)));
     CK(hipMemcpyAsync(c->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
     // bootstrapping key: upload coefficients, transform on device
