@@ -1,0 +1,90 @@
+"""BASELINE.json configs[3] across ranks: thfhe.circuits.knn_decision_sharded deals the train rows of the KNN decision
+(src/KNN_medical_data.cpp:681-691) over the ranks and gathers them with one all-reduce.  Two gloo ranks (CPU oracle playing the gate
+engine, reduced LWE dimension) must produce the very ciphertexts of the single-rank evaluation, and the plaintext KNN answer."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = """
+    import hashlib, json, os, sys
+    import numpy as np
+    sys.path.insert(0, {tests!r}); sys.path.insert(0, {pkg!r})
+    import oracle_lib as O
+    from thfhe import circuits as Cc
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    red = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        red = Cc.torch_all_reduce()
+    p = O.make_params("SK-128", n=10)
+    K = O.SKKeys(p, 4242, 2.0**-25, 2.0**-15)
+
+    class OracleKey:   # the gate engine of this rehearsal: same call surface as thfhe.CloudKey's host-buffer API
+        words = p.n + 1
+        orc = O.Oracle(p, K.bk, K.ksk)
+        def gates(self, op, x, y=None, z=None): return self.orc.gates(op, x, y, z)
+        def gates_mixed(self, ops, x, y):
+            out = np.zeros_like(x)
+            for op in np.unique(ops):
+                m = ops == op
+                out[m] = self.orc.gates(int(op), x[m], y[m])
+            return out
+
+    nb, ncol, ntrain = 6, 4, 3
+    test = [0, 17, 40, 1]
+    train = [[1, 20, 35, 1], [2, 3, 44, 0], [3, 16, 41, 1]]
+    bits = lambda v: [(v >> (nb - 1 - i)) & 1 for i in range(nb)]
+    enc = lambda vals, seed: K.encrypt_bits(np.array(sum((bits(v) for v in vals), [])), 2.0**-15, seed).reshape(len(vals), nb, -1)
+    e_test, e_train = enc(test, 1), np.stack([enc(r, 10 + j) for j, r in enumerate(train)])
+    thr, az, ao, lo = (enc([v], 100 + q)[0] for q, v in enumerate((ntrain // 2, 0, (1 << nb) - 1, 1)))
+    zero = K.encrypt_bits(np.array([0]), 2.0**-15, 200)[0]
+    st = {{}}
+    res = Cc.knn_decision_sharded(OracleKey(), Cc.KnnPlan(nb, ncol, ntrain), e_test, e_train, thr, az, ao, lo, zero, rank, world, red, st)
+    dec = lambda recs: int("".join("1" if b else "0" for b in K.decrypt_bits(recs)), 2)
+    h = hashlib.sha256(b"".join(np.ascontiguousarray(res[k]).tobytes() for k in ("decision", "count", "sorted_dists", "dists"))).hexdigest()
+    print(json.dumps(dict(rank=rank, sha=h, rows=st["my_rows"], dists=[dec(d) for d in res["dists"]], sorted=[dec(d) for d in res["sorted_dists"]],
+                          count=dec(res["count"]), decision=bool(K.decrypt_bits(res["decision"][None])[0]))), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run(tmp_path, world):
+    script = tmp_path / f"knn_rank_w{world}.py"
+    script.write_text(textwrap.dedent(SCRIPT.format(tests=os.path.join(ROOT, "tests"), pkg=os.path.join(ROOT, "torus-fhe_amd"))))
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="3")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for pr in procs:
+        so, se = pr.communicate(timeout=900)
+        assert pr.returncode == 0, se[-3000:]
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    return outs
+
+
+def test_knn_two_gloo_ranks_equal_single_rank(tmp_path):
+    one = run(tmp_path, 1)[0]
+    two = run(tmp_path, 2)
+    d = [abs(17 - r[1]) + abs(40 - r[2]) for r in [[1, 20, 35, 1], [2, 3, 44, 0], [3, 16, 41, 1]]]
+    assert one["dists"] == d and one["sorted"] == sorted(d) and one["count"] == 2 and one["decision"] is True
+    assert sorted(sum((o["rows"] for o in two), [])) == [0, 1, 2] and all(len(o["rows"]) >= 1 for o in two)   # both ranks worked
+    for o in two:
+        assert o["sha"] == one["sha"], "sharded evaluation differs from the single-rank ciphertexts"
+        assert (o["dists"], o["sorted"], o["count"], o["decision"]) == (one["dists"], one["sorted"], one["count"], one["decision"])

@@ -34,8 +34,8 @@ RANK_SCRIPT = """
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     rank = dist.get_rank()
     mode = {mode!r}
-    p = O.make_params("MK2", **{over!r})
-    s = O.SIGMAS["MK2"]
+    p = O.make_params({pset!r}, **{over!r})
+    s = O.SIGMAS[{pset!r}]
     K = O.MKKeys(p, 0x5EED0001, s["bk"], s["ks"])
     tp = thfhe.make_params(**p.as_dict())
     if mode == "oracle":
@@ -72,14 +72,14 @@ RANK_SCRIPT = """
 """
 
 
-def run_two_ranks(tmp_path, mode, over, gates, chunks, timeout):
+def run_two_ranks(tmp_path, mode, over, gates, chunks, timeout, pset="MK2", world=2):
     script = tmp_path / "rank.py"
     script.write_text(textwrap.dedent(RANK_SCRIPT.format(tests=os.path.join(ROOT, "tests"), pkg=os.path.join(ROOT, "torus-fhe_amd"),
-                                                         mode=mode, over=over, gates=gates, chunks=chunks)))
+                                                         mode=mode, over=over, gates=gates, chunks=chunks, pset=pset)))
     port = free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -94,6 +94,15 @@ def test_party_pipeline_two_gloo_ranks_vs_oracle(tmp_path):
     # reduced LWE dimension keeps the CPU oracle fast; ring degree, decomposition and key-switch shape are MK2's
     outs = run_two_ranks(tmp_path, "oracle", dict(n=12), gates=5, chunks=2, timeout=600)
     assert sorted(o["rank"] for o in outs) == [0, 1]
+    for o in outs:
+        assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt")), o
+
+
+def test_party_pipeline_four_gloo_ranks_mk4_shape_vs_oracle(tmp_path):
+    # BASELINE.json configs[4] shape: 4 parties, l = 3, Bgbit = 6, ks 5/2 (mk_api.jl:84-90) with a reduced LWE dimension; one rank per
+    # party, three pipeline hand-offs of the accumulator, broadcast from the last rank, 4-way all-gather of the key-switched parts
+    outs = run_two_ranks(tmp_path, "oracle", dict(n=8), gates=4, chunks=2, timeout=900, pset="MK4", world=4)
+    assert sorted(o["rank"] for o in outs) == [0, 1, 2, 3]
     for o in outs:
         assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt")), o
 

@@ -27,6 +27,30 @@ inline int ilog2(int x) {
     } while (0)
 
 #if defined(__HIPCC__)
+#ifdef THFHE_STAMPS
+// Diagnostic build only (make stamps -> torus-fhe_amd/lib/libthfhe_hip_stamps.so, never shipped): per-wave cycle totals of the phases of
+// the ring kernel's CMux loop, s_memtime deltas summed over all CMuxes; read back with thfhe_debug_read_stamps.
+#define THFHE_STAMP_STORAGE __device__ unsigned long long g_stamps[8 * 2048 * 8];
+#define STAMP_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime()
+#define STAMP(slot)                                              \
+    do {                                                         \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        st_acc[slot] += now_ - st_t;                             \
+        st_t = now_;                                             \
+    } while (0)
+#define STAMP_FLUSH(wg, wave)                                                                                  \
+    do {                                                                                                       \
+        if (lane == 0 && (wg) < 2048)                                                                          \
+            for (int q_ = 0; q_ < 6; q_++) g_stamps[(((size_t)(wg)) * 8 + (wave)) * 8 + q_] = st_acc[q_];       \
+    } while (0)
+#else
+#define THFHE_STAMP_STORAGE
+#define STAMP_DECL
+#define STAMP(slot)
+#define STAMP_FLUSH(wg, wave)
+#endif
+
+
 // Wave-level ordering point between two LDS segments.  One wavefront's DS instructions execute in issue order,
 // so no hardware barrier is needed -- this only stops the compiler from moving LDS accesses across the exchange.
 // The fences are scoped to the LDS address space so that global (bootstrapping-key) loads may be scheduled across them.

@@ -296,6 +296,9 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
 // alias the spectrum area: in phase 1 wave r transposes inside its own (not yet published) spectrum slot, in phase 2 a third
 // barrier frees the whole area before the eight inverse transforms use 8 KiB of it each.
 // ------------------------------------------------------------------------------------------------------
+THFHE_STAMP_STORAGE
+__device__ __forceinline__ void mk_pin() { asm volatile("" ::: "memory"); }  // memory operations do not move across this point
+
 template <int L>
 __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs a) {
     constexpr int ROWS = 2 * L;
@@ -320,18 +323,48 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
     const int o = wave >> 2, h = wave & 3;
     unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc) + o * 2048;
 
-    for (int i = 0; i < a.pn; i++) {
-        const int ai = bara[i];
-        if (ai == 0) continue;
-        const int a2n = ai & 4095;
+    // The key stream of a step is 2l rows x 2 half spectra = 4l chunks of 8 KiB per wave (l = 3: 96 KiB per wave, 768 KiB per workgroup
+    // and CMux -- the CU's vector-memory path carries ~45 B/clk, so it is busy for a good part of every step).  The chunks are
+    // requested two ahead of their use (registers bA / bB), and the first two chunks of the NEXT step are requested before this
+    // step's inverse transforms, so the memory pipeline never waits for the compute phases and the multiply never waits for a
+    // round trip of its own.  Compiler fences (mk_pin) keep the requests where they are written.
+    int i = 0;
+    while (i < a.pn && bara[i] == 0) i++;
+    cplx bA[8], bB[8];
+    auto chunk = [&](int step, int u) { return a.bk + mk_chunk_index_2k(step, u >> 1, h, o, ROWS) * 512 + (u & 1) * 512; };  // u = 2 r + half
+    if (i < a.pn) {
+        load8(lane, bA, chunk(i, 0));
+        load8(lane, bB, chunk(i, 1));
+    }
+    STAMP_DECL;
+    while (i < a.pn) {
+        const int a2n = bara[i] & 4095;
+        int inext = i + 1;
+        while (inext < a.pn && bara[inext] == 0) inext++;
+        const int inl = inext < a.pn ? inext : i;   // the last step re-requests its own chunks (unconditional loads: one register set)
         if (wave < ROWS) {
             cplx y0[8], y1[8];
             {
-                uint32_t t[32];
-                cplx z[16];
-                load_rotated32_hi(lane, sAcc + (wave / L) * 2048, a2n, offset, t);
-                digits_to_z16(t, (wave % L) + 1, Bgbit, z);
-                split2048(z, y0, y1);
+                // digits of the four coefficients (j, j + 512, j + 1024, j + 1536) that make one (y0[m], y1[m]) pair: no 32-word t[],
+                // no 16-point z[] alive next to the two half transforms
+                const int64_t *ap = sAcc + (wave / L) * 2048;
+                const int shift = 32 - ((wave % L) + 1) * Bgbit;
+                const uint32_t mask = (1u << Bgbit) - 1u;
+                const int32_t half = 1 << (Bgbit - 1);
+                constexpr double R = 0.70710678118654752440;
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    double d[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t t = (uint32_t)((rot_minus_self64_n<2048>(ap, lane + 64 * m + 512 * q, a2n) + offset) >> 32);
+                        d[q] = digit32(t, shift, mask, half);
+                    }
+                    // z[m] = (d0, d2) (coefficients j, j + 1024), z[m + 8] = (d1, d3); split2048: y0/1 = z[m] +- e^{i pi/4} z[m + 8]
+                    const cplx w{(d[1] - d[3]) * R, (d[1] + d[3]) * R};
+                    y0[m] = cplx{d[0] + w.re, d[2] + w.im};
+                    y1[m] = cplx{d[0] - w.re, d[2] - w.im};
+                }
             }
             cplx *xb = sSpec + wave * 1024;
             wave_fft_fwd_t<1>(lane, y0, xb, sT1[0], w64);
@@ -343,25 +376,31 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
                 xb[512 + m * 64 + lane] = y1[m];
             }
         }
+        STAMP(0);
         __syncthreads();  // spectra published; every rotated read of the accumulator is done
+        STAMP(1);
         cplx S0[8], S1[8];
 #pragma unroll
         for (int m = 0; m < 8; m++) S0[m] = S1[m] = cplx{0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            const cplx *B = a.bk + mk_chunk_index_2k(i, r, h, o, ROWS) * 512;
-            cplx b0[8], b1[8], z0[8], z1[8];
-            load8(lane, b0, B);
-            load8(lane, b1, B + 512);
+        for (int u = 0; u < 2 * ROWS; u += 2) {
+            cplx z[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                z0[m] = sSpec[r * 1024 + m * 64 + lane];
-                z1[m] = sSpec[r * 1024 + 512 + m * 64 + lane];
-            }
-            mac8r(S0, z0, b0);
-            mac8r(S1, z1, b1);
+            for (int m = 0; m < 8; m++) z[m] = sSpec[(u >> 1) * 1024 + m * 64 + lane];
+            mac8r(S0, z, bA);
+            mk_pin();
+            load8(lane, bA, u + 2 < 2 * ROWS ? chunk(i, u + 2) : chunk(inl, 0));
+            mk_pin();
+#pragma unroll
+            for (int m = 0; m < 8; m++) z[m] = sSpec[(u >> 1) * 1024 + 512 + m * 64 + lane];
+            mac8r(S1, z, bB);
+            mk_pin();
+            load8(lane, bB, u + 2 < 2 * ROWS ? chunk(i, u + 3) : chunk(inl, 1));
+            mk_pin();
         }
+        STAMP(2);
         __syncthreads();  // spectra consumed: the area is transpose scratch from here on
+        STAMP(4);
         {
             cplx *xb = sSpec + wave * 512;
             wave_fft_inv_t<1>(lane, S0, xb, sT1[0], w64);
@@ -377,8 +416,12 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
                 atomicAdd(accu + q + 1536, (unsigned long long)round_i64(hi[m].im) << (16 * h));
             }
         }
+        STAMP(3);
         __syncthreads();  // accumulator updated and scratch free before the next rotation
+        STAMP(5);
+        i = inext;
     }
+    STAMP_FLUSH(blockIdx.x, wave);
     if (a.acc_out) {
         for (int q = threadIdx.x; q < 4096; q += 512) a.acc_out[job * 4096 + q] = sAcc[q];
     } else if (wave == 0) {
@@ -876,6 +919,11 @@ int thfhe_mk_prologue_dev(thfhe_mk_ctx *c, int op, int which, const int32_t *d0,
     THFHE_HIP(hipGetLastError());
     return THFHE_OK;
 }
+#ifdef THFHE_STAMPS
+int thfhe_debug_read_stamps_mk(unsigned long long *dst, size_t count) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 int thfhe_mk_set_pair_threshold(thfhe_mk_ctx *c, long max_single_jobs) {
     if (!c || max_single_jobs < 0) return thfhe_fail(THFHE_E_INVALID, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);

@@ -150,6 +150,96 @@ def knn_classify(cir, test_row, train_rows, threshold, all_zero, all_one, lsb_on
     return cir.gate(XOR, diff[0], all_zero[0]), count, sdists
 
 
+# ---- the KNN decision sharded over ranks (BASELINE.json configs[3]; src/KNN_medical_data.cpp:676-732) ------------------------------
+class KnnPlan:
+    """The reference's KNN decision for one test record, cut the way its `#pragma omp parallel for` over train rows (:681-691) cuts it:
+      phase 1  per train row: distance_bw_data to the test record + the MUX copy of the row -- independent rows, sharded over ranks;
+      phase 2  sort_with_distance, vote over the label column of the K = n_train nearest, decision bit -- one sequential chain,
+               evaluated by every rank on the gathered rows (replicated keys; 855 of its levels hold 1-3 gates, nothing to shard).
+    Inputs (MSB-first bit records): the test record, the train rows, and the constants (threshold, allZero, allOne, lsbOne, zero).
+    One rank (world = 1) evaluates the very same two DAGs, so the sharded result equals the single-rank result bit for bit."""
+
+    def __init__(self, nb, ncol, ntrain):
+        self.nb, self.ncol, self.ntrain = nb, ncol, ntrain
+
+    def phase1(self, n_rows):
+        """DAG for n_rows train rows: inputs = test[ncol], rows[n_rows][ncol], allZero, allOne, lsbOne, zero."""
+        c = Circuit()
+        test = [c.inputs(self.nb) for _ in range(self.ncol)]
+        rows = [[c.inputs(self.nb) for _ in range(self.ncol)] for _ in range(n_rows)]
+        all_zero, all_one, lsb_one = c.inputs(self.nb), c.inputs(self.nb), c.inputs(self.nb)
+        zero = c.inputs(1)[0]
+        dist = [distance_bw_data(c, test[:self.ncol - 1], r[:self.ncol - 1], all_zero, all_one, lsb_one, zero) for r in rows]
+        copies = [[copy_through_mux(c, all_one, w) for w in r] for r in rows]
+        return c, dist, copies
+
+    def phase2(self):
+        """DAG on the gathered rows: inputs = rows[ntrain][ncol], dists[ntrain], threshold, allZero, allOne, lsbOne, zero."""
+        c = Circuit()
+        rows = [[c.inputs(self.nb) for _ in range(self.ncol)] for _ in range(self.ntrain)]
+        dists = [c.inputs(self.nb) for _ in range(self.ntrain)]
+        thr, all_zero, all_one, lsb_one = (c.inputs(self.nb) for _ in range(4))
+        zero = c.inputs(1)[0]
+        srows, sdists = sort_with_distance(c, rows, dists, all_zero, all_one, lsb_one, zero)
+        count = list(all_zero)
+        for j in range(self.ntrain):
+            count, _ = full_adder(c, count, srows[j][self.ncol - 1], zero)
+        diff = difference(c, thr, count, all_one, lsb_one, zero)
+        decision = c.gate(XOR, diff[0], all_zero[0])
+        return c, decision, count, sdists, srows
+
+
+def knn_decision_sharded(ck, plan, test, train, threshold, all_zero, all_one, lsb_one, zero, rank=0, world=1, all_reduce=None, stats=None):
+    """Evaluate the KNN decision with the train rows of phase 1 dealt round-robin over `world` ranks (every rank holds the keys).
+    test: int32[ncol][nb][words]; train: int32[ntrain][ncol][nb][words]; threshold / all_zero / all_one / lsb_one: int32[nb][words];
+    zero: int32[words].  all_reduce(np.ndarray) -> np.ndarray sums an int32 array over the ranks (torch.distributed all_reduce over
+    RCCL or gloo; every row is produced by exactly one rank, so the sum IS the gather); None is allowed only for world = 1.
+    Returns dict(decision=record, count=records[nb], sorted_dists=records[ntrain][nb], dists=records[ntrain][nb])."""
+    nb, ncol, ntrain = plan.nb, plan.ncol, plan.ntrain
+    words = ck.words
+    test = np.asarray(test, np.int32).reshape(ncol, nb, words)
+    train = np.asarray(train, np.int32).reshape(ntrain, ncol, nb, words)
+    consts = [np.asarray(v, np.int32).reshape(nb, words) for v in (all_zero, all_one, lsb_one)]
+    zero = np.asarray(zero, np.int32).reshape(1, words)
+    mine = [j for j in range(ntrain) if j % world == rank]
+    gathered = np.zeros((ntrain, ncol + 1, nb, words), np.int32)   # [row][its ncol words, then its distance]
+    st1 = {}
+    if mine:
+        c1, dist, copies = plan.phase1(len(mine))
+        in1 = np.concatenate([test.reshape(-1, words), train[mine].reshape(-1, words)] + consts + [zero])
+        v1 = evaluate(ck, c1, in1, st1)
+        for q, j in enumerate(mine):
+            for col in range(ncol):
+                gathered[j, col] = v1[copies[q][col]]
+            gathered[j, ncol] = v1[dist[q]]
+    if world > 1:
+        if all_reduce is None:
+            raise ValueError("knn_decision_sharded: world > 1 needs an all_reduce callable")
+        gathered = np.asarray(all_reduce(gathered), np.int32).reshape(gathered.shape)
+    c2, decision, count, sdists, _ = plan.phase2()
+    thr = np.asarray(threshold, np.int32).reshape(nb, words)
+    in2 = np.concatenate([gathered[:, :ncol].reshape(-1, words), gathered[:, ncol].reshape(-1, words), thr] + consts + [zero])
+    st2 = {}
+    v2 = evaluate(ck, c2, in2, st2)
+    if stats is not None:
+        stats.update(phase1=st1, phase2=st2, my_rows=mine)
+    return dict(decision=v2[decision], count=v2[count], sorted_dists=np.stack([v2[w] for w in sdists]), dists=gathered[:, ncol])
+
+
+def torch_all_reduce(device=None):
+    """all_reduce callable for knn_decision_sharded over torch.distributed (backend nccl = RCCL: pass the rank's cuda device)."""
+    import torch
+    import torch.distributed as dist
+
+    def f(a):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t)
+        return t.cpu().numpy()
+    return f
+
+
 # ---- the reference's multi-key integer circuits (3gen_mk_gates.jl; bit vectors LSB-first, mk_api.jl:563-576) ----------
 def mk_add_3gen(cir, a, b, cin):
     """mk_add_3gen / mk_add_3gen_v2, 3gen_mk_gates.jl:183-220."""
