@@ -41,6 +41,8 @@ PARAM_SETS = {
     "MK2": dict(n=520, N=1024, k=1, l=2, Bgbit=7, ks_t=3, ks_basebit=3, torus_bits=64, parties=2),
     "MK3": dict(n=510, N=1024, k=1, l=2, Bgbit=7, ks_t=5, ks_basebit=2, torus_bits=64, parties=3),
     "MK4": dict(n=510, N=1024, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
+    "MK5": dict(n=520, N=1024, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=5),   # mk_api.jl:98-104
+    "MK8": dict(n=540, N=1024, k=1, l=4, Bgbit=4, ks_t=5, ks_basebit=2, torus_bits=64, parties=8),   # mk_api.jl:140-146
     "MK4-N2048": dict(n=510, N=2048, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
     # CCS scheme (mk_bootstrap / mk_gate_nand): mktfhe_parameters_2party / _4party, J/mk_api.jl:4-10,56-62
     "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
@@ -55,6 +57,8 @@ SIGMAS = {
     "MK2": dict(lwe=2.0 ** -13.52, bk=2.0 ** -30.70, ks=2.0 ** -13.52),
     "MK3": dict(lwe=2.0 ** -13.26, bk=2.0 ** -30.70, ks=2.0 ** -13.26),
     "MK4": dict(lwe=2.0 ** -13.26, bk=2.0 ** -30.70, ks=2.0 ** -13.26),
+    "MK5": dict(lwe=2.0 ** -13.52, bk=2.0 ** -30.70, ks=2.0 ** -13.52),
+    "MK8": dict(lwe=2.0 ** -14.04, bk=2.0 ** -30.70, ks=2.0 ** -14.04),
     "MK4-N2048": dict(lwe=2.0 ** -13.26, bk=2.0 ** -30.70, ks=2.0 ** -13.26),
     "CCS2": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS4": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),

@@ -85,6 +85,37 @@ def test_mk4_bit_exact(O):
     ck.close()
 
 
+@pytest.mark.parametrize("name,n", [("MK5", 520), ("MK8", 96)])
+def test_mk5_mk8_bit_exact(O, name, n):
+    # mktfhe_parameters_5party_3gen (P = 5, l = 3, Bgbit = 6; full size) and mktfhe_parameters_8party_3gen (P = 8, l = 4, Bgbit = 4:
+    # eight digit rows, key rows streamed through a register window; LWE dimension reduced to keep the 8-party oracle in seconds)
+    # J/mk_api.jl:98-104, 140-146.  Small batches take the one-gate-per-workgroup kernel, 300 gates the two-gate kernel (l <= 3).
+    import thfhe
+    p = O.make_params(name, n=n)
+    s = O.SIGMAS[name]
+    K = O.MKKeys(p, 79, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    ck = thfhe.MKCloudKey(thfhe.make_params(name, n=n), K.bk, K.ksk, device=0)
+    a = np.array([0, 1, 1, 0, 1]); b = np.array([1, 1, 0, 0, 1]); c = np.array([1, 0, 1, 1, 0])
+    ca, cb, cc = (K.encrypt_bits(v, s["lwe"], 11 + q) for q, v in enumerate((a, b, c)))
+    for op in (O.NAND, O.XOR):
+        got = ck.gates(op, ca, cb)
+        assert np.array_equal(got, orc.gates(op, ca, cb)), (name, op)
+    got = ck.gates(O.NAND, ca, cb)
+    assert np.array_equal(K.decrypt_bits(got), ~(a.astype(bool) & b.astype(bool)))
+    assert np.array_equal(ck.gates(O.AND3, ca, cb, cc), orc.gates(O.AND3, ca, cb, cc))
+    assert np.array_equal(ck.gates(O.MUX, ca, cb, cc), orc.gates(O.MUX, ca, cb, cc))
+    if name == "MK5":   # the throughput kernel on an odd batch
+        rng = np.random.default_rng(4)
+        B = 301
+        xa, xb = K.encrypt_bits(rng.integers(0, 2, B), s["lwe"], 21), K.encrypt_bits(rng.integers(0, 2, B), s["lwe"], 22)
+        got = ck.gates(O.NAND, xa, xb)
+        idx = np.sort(rng.choice(B, 24, replace=False))
+        assert np.array_equal(got[idx], orc.gates(O.NAND, xa[idx], xb[idx]))
+        assert np.array_equal(K.decrypt_bits(got), ~(K.decrypt_bits(xa) & K.decrypt_bits(xb)))
+    ck.close()
+
+
 def test_mk_n2048_reduced_n_all_gates_bit_exact(O):
     # ring degree 2048 (BASELINE configs[4]): radix-2 split + two twisted 512-point transforms; l = 3 and l = 2 shapes
     import thfhe

@@ -157,9 +157,12 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a
 #pragma unroll
             for (int m = 0; m < 8; m++) sSpec[wave][m * 64 + lane] = z[m];
         }
-        cplx B[ROWS][8];
+        // key rows in registers: all 2l of them up to l = 3 (192 VGPRs); from l = 4 on (the 8-party set: 8 rows = 256 VGPRs, which
+        // spilled 332 B/lane) a window of PRE rows, refilled as the multiply walks the rows
+        constexpr int PRE = ROWS <= 6 ? ROWS : 4;
+        cplx B[PRE][8];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) load8(lane, B[r], a.bk + mk_chunk_index(i, r, h, o, ROWS) * 512);
+        for (int r = 0; r < PRE; r++) load8(lane, B[r], a.bk + mk_chunk_index(i, r, h, o, ROWS) * 512);
         __syncthreads();  // spectra published; every rotated read of the accumulator is done
         cplx S[8];
 #pragma unroll
@@ -169,7 +172,8 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a
             cplx z[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) z[m] = sSpec[r][m * 64 + lane];
-            mac8r(S, z, B[r]);
+            mac8r(S, z, B[r % PRE]);
+            if (r + PRE < ROWS) load8(lane, B[r % PRE], a.bk + mk_chunk_index(i, r + PRE, h, o, ROWS) * 512);
         }
         wave_fft_inv_s(lane, S, sX[wave], sT1, w64);
 #pragma unroll

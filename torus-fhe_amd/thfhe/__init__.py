@@ -42,6 +42,8 @@ PARAM_SETS = {
     "MK2": dict(n=520, N=1024, k=1, l=2, Bgbit=7, ks_t=3, ks_basebit=3, torus_bits=64, parties=2),
     "MK3": dict(n=510, N=1024, k=1, l=2, Bgbit=7, ks_t=5, ks_basebit=2, torus_bits=64, parties=3),
     "MK4": dict(n=510, N=1024, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
+    "MK5": dict(n=520, N=1024, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=5),   # mk_api.jl:98-104
+    "MK8": dict(n=540, N=1024, k=1, l=4, Bgbit=4, ks_t=5, ks_basebit=2, torus_bits=64, parties=8),   # mk_api.jl:140-146
     # BASELINE.json configs[4] wording ("4-party 3-gen MK-TFHE, N=2048 l=3"): the reference's 4-party set on the larger ring
     "MK4-N2048": dict(n=510, N=2048, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
     # CCS scheme (mk_bootstrap / mk_gate_nand): mktfhe_parameters_2party / _4party, mk_api.jl:4-10,56-62
