@@ -196,6 +196,22 @@ int thfhe_partial_decrypt(thfhe_poly_ctx *ctx, const int32_t *key_share, const i
 int thfhe_final_decrypt(thfhe_poly_ctx *ctx, const int32_t *tlwe_b, const int32_t *partials /*[t][count][N]*/, int t, int32_t *result, int32_t *bits,
                         size_t count);
 
+/* ---- multi-key KEY GENERATION arithmetic on the device --------------------------------------------------------------
+ * Exact multiply-accumulate of small-coefficient polynomials with torus polynomials, the only non-trivial arithmetic of
+ *   tgsw_encrypt_3gen                3-gen-mk-tfhe/src/tgsw_3gen.jl:41-95     part_1..4 = r1 (*) B, r2 (*) B, r2 (*) A, r1 (*) A  (+ m g + e)
+ *   PublicKey / CommonPubKey_3gen    3-gen-mk-tfhe/src/mk_internals.jl:266-345 b = z (*) a + e ; B = sum of the parties' b
+ *   mk_tgsw_encrypt (CCS)            3-gen-mk-tfhe/src/mk_internals.jl:390-446 d1 = r (*) a + m g + e ; f0 = s (*) f1 + r g + e
+ * The randomness (keys, masks, Gaussian noise) is an INPUT, so the device result equals the host key generation bit for bit.
+ *   out[j] = addend[j] + sum over the terms (j, s, t, sign) of sign * small[s] (*) torus[t]     mod X^N + 1, mod 2^torus_bits
+ *   small  int32[n_small][N], |coefficient| <= 4096;  torus / addend / out  int32 or int64 [.][N] by torus_bits;
+ *   terms  int32[n_terms][4] = (out, small, torus, +1 | -1), outputs in ascending order; addend may be NULL.
+ * N = 1024 (torus_bits 32 or 64) and N = 2048 (torus_bits 64). */
+typedef struct thfhe_pm_ctx thfhe_pm_ctx;
+int thfhe_pm_ctx_create(int device, int N, int torus_bits, thfhe_pm_ctx **out);
+void thfhe_pm_ctx_destroy(thfhe_pm_ctx *ctx);
+int thfhe_pm_mac(thfhe_pm_ctx *ctx, const int32_t *small, size_t n_small, const void *torus, size_t n_torus, const int32_t *terms, size_t n_terms,
+                 const void *addend, void *out, size_t n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,9 @@ SIGNATURES = {
     "thfhe_tlwe_from_lwe": (C.c_int, [_vp, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_partial_decrypt": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_final_decrypt": (C.c_int, [_vp, _i32p, _i32p, C.c_int, _i32p, _i32p, C.c_size_t]),
+    "thfhe_pm_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "thfhe_pm_ctx_destroy": (None, [_vp]),
+    "thfhe_pm_mac": (C.c_int, [_vp, _i32p, C.c_size_t, _vp, C.c_size_t, _i32p, C.c_size_t, _vp, _vp, C.c_size_t]),
     "thfhe_mk_ctx_create": (C.c_int, [C.POINTER(Params), _i64p, _i32p, C.c_int, C.POINTER(_vp)]),
     "thfhe_mk_ctx_destroy": (None, [_vp]),
     "thfhe_mk_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
@@ -453,6 +456,37 @@ class MKCloudKey:
         ms = (C.c_float * 4)()
         _check(lib().thfhe_mk_last_timings(self.h, ms))
         return dict(prologue_ms=ms[0], blind_rotate_ms=ms[1], keyswitch_ms=ms[2], total_ms=ms[3])
+
+
+class PolyMac:
+    """Device engine for the key-generation products (thfhe_pm_mac): out[j] = addend[j] + sum_terms sign * small[s] (*) torus[t], exact."""
+
+    def __init__(self, N, torus_bits, device=0):
+        h = _vp()
+        _check(lib().thfhe_pm_ctx_create(device, N, torus_bits, C.byref(h)))
+        self.h, self._destroy, self.N, self.dtype = h, lib().thfhe_pm_ctx_destroy, N, (np.int32 if torus_bits == 32 else np.int64)
+
+    def close(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and getattr(self, "_destroy", None) is not None:
+            self._destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def mac(self, small, torus, terms, n_out, addend=None):
+        small = np.ascontiguousarray(small, np.int32).reshape(-1, self.N)
+        torus = np.ascontiguousarray(torus).view(self.dtype).reshape(-1, self.N)
+        terms = np.ascontiguousarray(terms, np.int32).reshape(-1, 4)
+        out = np.empty((n_out, self.N), self.dtype)
+        if addend is not None:
+            addend = np.ascontiguousarray(addend).view(self.dtype).reshape(n_out, self.N)
+        _check(lib().thfhe_pm_mac(self.h, _p32(small), small.shape[0], torus.ctypes.data_as(_vp), torus.shape[0], _p32(terms), terms.shape[0],
+                                  addend.ctypes.data_as(_vp) if addend is not None else None, out.ctypes.data_as(_vp), n_out))
+        return out
 
 
 class CCSCloudKey:

@@ -179,10 +179,16 @@ def rand_ternary(rng, shape):
 class MKSecretKeySet:
     """3-gen multi-key material following 3-gen-mk-tfhe/multikey_3gen.jl:15-30."""
 
-    def __init__(self, params, seed=0x5EED0001, sigma_lwe=None, sigma_bk=2.0**-30.70, sigma_ks=None):
+    def __init__(self, params, seed=0x5EED0001, sigma_lwe=None, sigma_bk=2.0**-30.70, sigma_ks=None, device=None):
+        """device = None: the ring products run on the host (float64 GEMMs on 22-bit limbs); device = d: on MI355X number d
+        (thfhe.PolyMac / thfhe_pm_mac).  The random stream is drawn identically either way, so both give the same key material bit for bit."""
         p = self.params = params
         assert p.k == 1 and p.torus_bits == 64
         rng = np.random.default_rng(seed)
+        pm = None
+        if device is not None:
+            from . import PolyMac
+            pm = PolyMac(p.N, 64, device)
         P, n, N, l = p.parties, p.n, p.N, p.l
         self.sigma_lwe = sigma_lwe if sigma_lwe is not None else 2.0**-13.52
         sigma_ks = sigma_ks if sigma_ks is not None else self.sigma_lwe
@@ -191,8 +197,10 @@ class MKSecretKeySet:
         crp = rng.integers(-2**63, 2**63, size=N, dtype=np.int64)             # CRP_3gen(a_same = true)
         # PublicKey b_q[i] = z_q (*) a + e ; CommonPubKey B[i] = sum_q b_q[i]
         B = np.zeros((l, N), np.uint64)
+        if pm is not None:   # z_q (*) a for all parties in one device call
+            za_all = pm.mac(self.rlwe_keys, crp[None, :], [(q, q, 0, 1) for q in range(P)], P).view(np.uint64)
         for q in range(P):
-            za = polymul_small64(crp[None, :], self.rlwe_keys[q])[0].view(np.uint64)
+            za = za_all[q] if pm is not None else polymul_small64(crp[None, :], self.rlwe_keys[q])[0].view(np.uint64)
             B += za[None, :] + dtot64(rng.standard_normal((l, N)) * sigma_bk).view(np.uint64)
         # tgsw_encrypt_3gen for every key bit
         bk = np.empty((P, n, 4, l, N), np.uint64)
@@ -200,19 +208,36 @@ class MKSecretKeySet:
         for lv in range(l):
             r1 = rand_ternary(rng, (P * n, N))
             r2 = rand_ternary(rng, (P * n, N))
-            MB = negacyclic_matrix_u64(B[lv])
-            MA = negacyclic_matrix_u64(crp.view(np.uint64))
             e = [dtot64(rng.standard_normal((P * n, N)) * sigma_bk).view(np.uint64) for _ in range(4)]
             m = self.lwe_keys.reshape(-1).astype(np.uint64)
-            P1 = small_times_torus64(r1, MB) + e[0]
-            P2 = small_times_torus64(r2, MB) + e[1]
-            P3 = small_times_torus64(r2, MA) + e[2]
-            P4 = small_times_torus64(r1, MA) + e[3]
-            P1[:, 0] += m << g[lv]
-            P3[:, 0] += m << g[lv]
+            if pm is not None:
+                # tgsw_encrypt_3gen on the device: outputs (bit, part), small operands [r1 rows, r2 rows], torus operands [B_lv, A];
+                # the noise and the message m g on coefficient 0 of part_1 / part_3 travel as the addend
+                K = P * n
+                add = np.stack(e, axis=1).copy()                      # [K][4][N]
+                add[:, 0, 0] += m << g[lv]
+                add[:, 2, 0] += m << g[lv]
+                sm = np.concatenate([r1, r2]).astype(np.int32)
+                terms = np.empty((K, 4, 4), np.int32)
+                kk = np.arange(K)
+                for part, (which, tor) in enumerate(((0, 0), (1, 0), (1, 1), (0, 1))):   # P1 = r1 B, P2 = r2 B, P3 = r2 A, P4 = r1 A
+                    terms[:, part] = np.stack([kk * 4 + part, which * K + kk, np.full(K, tor), np.ones(K, np.int64)], axis=1)
+                res = pm.mac(sm, np.stack([B[lv], crp.view(np.uint64)]), terms.reshape(-1, 4), 4 * K, add.reshape(-1, N)).view(np.uint64).reshape(K, 4, N)
+                P1, P2, P3, P4 = (res[:, q] for q in range(4))
+            else:
+                MB = negacyclic_matrix_u64(B[lv])
+                MA = negacyclic_matrix_u64(crp.view(np.uint64))
+                P1 = small_times_torus64(r1, MB) + e[0]
+                P2 = small_times_torus64(r2, MB) + e[1]
+                P3 = small_times_torus64(r2, MA) + e[2]
+                P4 = small_times_torus64(r1, MA) + e[3]
+                P1[:, 0] += m << g[lv]
+                P3[:, 0] += m << g[lv]
             for part, arr in enumerate((P1, P2, P3, P4)):
                 bk[:, :, part, lv, :] = arr.reshape(P, n, N)
         self.bk = bk.view(np.int64)
+        if pm is not None:
+            pm.close()
         self.ksk = np.stack([gen_keyswitch_key(rng, self.rlwe_keys[q], self.lwe_keys[q], p.ks_t, p.ks_basebit, sigma_ks)
                              for q in range(P)])
 
@@ -247,17 +272,27 @@ class CCSSecretKeySet:
     key, PublicKey b_i = s (*) a_i + e (mk_internals.jl:209-245), the uni-encryption (d1, f0, f1) of every key bit
     (mk_tgsw_encrypt, :390-448; c0, c1, d0 are not read by UniProduct_old) and a KeyswitchKey."""
 
-    def __init__(self, params, seed=0x5EED0001, sigma_lwe=3.05e-5, sigma_bk=3.72e-9, sigma_ks=3.05e-5):
+    def __init__(self, params, seed=0x5EED0001, sigma_lwe=3.05e-5, sigma_bk=3.72e-9, sigma_ks=3.05e-5, device=None):
+        """device: as MKSecretKeySet (None = host products, d = MI355X number d; identical key material)."""
         p = self.params = params
         assert p.k == 1 and p.torus_bits == 32
         rng = np.random.default_rng(seed)
+        pm = None
+        if device is not None:
+            from . import PolyMac
+            pm = PolyMac(p.N, 32, device)
         P, n, N, l = p.parties, p.n, p.N, p.l
         self.sigma_lwe = sigma_lwe
         self.lwe_keys = rng.integers(0, 2, (P, n)).astype(np.int32)
         self.rlwe_keys = rng.integers(0, 2, (P, N)).astype(np.int32)
         self.crs = rng.integers(-2**31, 2**31, size=(l, N), dtype=np.int64).astype(np.int32)                 # SharedKey.a
         gauss = lambda shape: dtot32(rng.standard_normal(shape) * sigma_bk).astype(np.int64)
-        self.pk = np.stack([(polymul_small32(self.crs, self.rlwe_keys[q]).astype(np.int64) + gauss((l, N))) for q in range(P)])
+        if pm is not None:   # PublicKey b_i = s (*) a_i + e: outputs (party, level), small = the parties' RLWE keys, torus = the shared a_i
+            noise = np.stack([gauss((l, N)) for q in range(P)])
+            terms = [(q * l + i, q, i, 1) for q in range(P) for i in range(l)]
+            self.pk = pm.mac(self.rlwe_keys, self.crs, terms, P * l, noise.astype(np.uint32).view(np.int32).reshape(-1, N)).reshape(P, l, N).astype(np.int64)
+        else:
+            self.pk = np.stack([(polymul_small32(self.crs, self.rlwe_keys[q]).astype(np.int64) + gauss((l, N))) for q in range(P)])
         self.pk = self.pk.astype(np.uint32).view(np.int32)
         g = np.array([1 << (32 - (i + 1) * p.Bgbit) for i in range(l)], np.int64)
         bk = np.empty((P, n, 3, l, N), np.int64)
@@ -265,15 +300,32 @@ class CCSSecretKeySet:
             r = rng.integers(0, 2, (n, N)).astype(np.int64)                                                   # the shared randomness r, one per key bit
             f1 = rng.integers(-2**31, 2**31, size=(n, l, N), dtype=np.int64).astype(np.int32)
             for i in range(l):
-                # d1_i = e + r (*) a_i + m g_i ; r (*) a_i = rows of r times the fixed polynomial a_i
-                ra = (r.astype(np.float64) @ negacyclic_matrix((self.crs[i].astype(np.int64) & 0xFFFF).astype(np.float64))).astype(np.int64) \
-                    + ((r.astype(np.float64) @ negacyclic_matrix((self.crs[i].astype(np.int64) >> 16).astype(np.float64))).astype(np.int64) << 16)
-                d1 = ra + gauss((n, N))
-                d1[:, 0] += self.lwe_keys[q].astype(np.int64) * g[i]
-                bk[q, :, 0, i, :] = d1
-                bk[q, :, 1, i, :] = polymul_small32(f1[:, i, :], self.rlwe_keys[q]).astype(np.int64) + gauss((n, N)) + r * g[i]   # f0_i = e + s (*) f1_i + r g_i
+                e_d1, e_f0 = gauss((n, N)), gauss((n, N))
+                if pm is not None:
+                    # mk_tgsw_encrypt on the device: d1_i = r (*) a_i + (e + m g_i), f0_i = s (*) f1_i + (e + r g_i); small = [r rows, s],
+                    # torus = [a_i, f1_i rows], outputs (bit, d1 | f0)
+                    add = np.stack([e_d1, e_f0 + r * g[i]], axis=1)
+                    add[:, 0, 0] += self.lwe_keys[q].astype(np.int64) * g[i]
+                    kk = np.arange(n)
+                    terms = np.empty((n, 2, 4), np.int32)
+                    terms[:, 0] = np.stack([2 * kk, kk, np.zeros(n, np.int64), np.ones(n, np.int64)], axis=1)
+                    terms[:, 1] = np.stack([2 * kk + 1, np.full(n, n), 1 + kk, np.ones(n, np.int64)], axis=1)
+                    res = pm.mac(np.concatenate([r, self.rlwe_keys[q][None, :]]).astype(np.int32), np.concatenate([self.crs[i][None, :], f1[:, i, :]]),
+                                 terms.reshape(-1, 4), 2 * n, add.astype(np.uint32).view(np.int32).reshape(-1, N)).reshape(n, 2, N)
+                    bk[q, :, 0, i, :] = res[:, 0]
+                    bk[q, :, 1, i, :] = res[:, 1]
+                else:
+                    # d1_i = e + r (*) a_i + m g_i ; r (*) a_i = rows of r times the fixed polynomial a_i
+                    ra = (r.astype(np.float64) @ negacyclic_matrix((self.crs[i].astype(np.int64) & 0xFFFF).astype(np.float64))).astype(np.int64) \
+                        + ((r.astype(np.float64) @ negacyclic_matrix((self.crs[i].astype(np.int64) >> 16).astype(np.float64))).astype(np.int64) << 16)
+                    d1 = ra + e_d1
+                    d1[:, 0] += self.lwe_keys[q].astype(np.int64) * g[i]
+                    bk[q, :, 0, i, :] = d1
+                    bk[q, :, 1, i, :] = polymul_small32(f1[:, i, :], self.rlwe_keys[q]).astype(np.int64) + e_f0 + r * g[i]   # f0_i = e + s (*) f1_i + r g_i
                 bk[q, :, 2, i, :] = f1[:, i, :]
         self.bk = bk.astype(np.uint32).view(np.int32)
+        if pm is not None:
+            pm.close()
         self.ksk = np.stack([gen_keyswitch_key(rng, self.rlwe_keys[q], self.lwe_keys[q], p.ks_t, p.ks_basebit, sigma_ks) for q in range(P)])
 
     encrypt = MKSecretKeySet.encrypt
