@@ -212,6 +212,29 @@ void thfhe_pm_ctx_destroy(thfhe_pm_ctx *ctx);
 int thfhe_pm_mac(thfhe_pm_ctx *ctx, const int32_t *small, size_t n_small, const void *torus, size_t n_torus, const int32_t *terms, size_t n_terms,
                  const void *addend, void *out, size_t n_out);
 
+/* ---- KMS multi-key scheme: mk_bootstrap_new / mk_gate_nand_new ----------------------------------------------
+ * reference: 3-gen-mk-tfhe/src/new_mk_internals.jl (mk_ith_blind_rotate :210-225, mk_lev_rlwe_mul :185-207, UniProduct_new :85-127,
+ * mk_bootstrap_new :321-325), tlev.jl, new_mk_gates.jl:1-7, parameter sets mk_api.jl:12-30,64-82,120-138 (ring degree 2048, Torus64).
+ * The context holds the parties' TGSW bootstrapping keys (spectral, device) and key-switch keys:
+ *   gsw  int64[P][n][2 l_gsw][2][N]  row = block * l_gsw + level, column 0 = mask, 1 = body (coefficient domain)
+ *   ksk  int32[P][N][t][base-1][n+1]
+ * thfhe_kms_tlev_rotate   <- mk_ith_blind_rotate: for `count` gates, party `party`: bara int32[count][n] (the party's mod-switched mask
+ *                            words) -> lev int64[count][l_lev][2][N], the rotated TLev accumulator (mask, body per level)
+ * thfhe_kms_keyswitch     <- mk_keyswitch (mk_internals.jl:714-728): u int32[count][P N + 1] -> out int32[count][P n + 1]
+ * The products between the two (tlev_extern_mul, UniProduct_new) go through thfhe_pm_mac under the host layer (thfhe/kms.py). */
+typedef struct {
+    int32_t n, N, parties;
+    int32_t l_gsw, bg_gsw;
+    int32_t l_lev, bg_lev;
+    int32_t l_uni, bg_uni;
+    int32_t ks_t, ks_basebit;
+} thfhe_kms_params;
+typedef struct thfhe_kms_ctx thfhe_kms_ctx;
+int thfhe_kms_ctx_create(const thfhe_kms_params *p, const int64_t *gsw, const int32_t *ksk, int device, thfhe_kms_ctx **out);
+void thfhe_kms_ctx_destroy(thfhe_kms_ctx *ctx);
+int thfhe_kms_tlev_rotate(thfhe_kms_ctx *ctx, int party, const int32_t *bara, int64_t *lev, size_t count);
+int thfhe_kms_keyswitch(thfhe_kms_ctx *ctx, const int32_t *u, int32_t *out, size_t count);
+
 #ifdef __cplusplus
 }
 #endif

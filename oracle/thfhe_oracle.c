@@ -1169,3 +1169,163 @@ void oracle_keygen_ccs(const oracle_params *p, uint64_t seed, double sigma_bk, d
         gen_ksk(&r, rlwe_keys + (size_t)q * N, N, lwe_keys + (size_t)q * n, n, p->ks_t, p->ks_basebit, sigma_ks, ksk + (size_t)q * per_party);
     }
 }
+
+/* ============================================================================================
+ * KMS multi-key scheme: mk_bootstrap_new / mk_gate_nand_new      J/new_mk_internals.jl, J/tlev.jl, J/new_mk_gates.jl
+ * (Torus64 ring, k = 1).  Three gadget families: gsw (the per-party single-key TGSW blind rotation of a TLev accumulator),
+ * lev (the TLev accumulator itself) and uni (the uni-encryption that relinearises from the party's fresh key to the joint key).
+ * Tables (coefficient domain, int64):  gsw [P][n][2 l_gsw][2][N] (row = block j * l + level, column 0 = mask, 1 = body);
+ *   uni [P][3][l_uni][N] = d1, f0, f1 of mk_tgsw_encrypt (J/mk_internals.jl:390-446);  pk [P][l_uni][N];  crs [l_uni][N];
+ *   ksk int32 [P][N][t][base-1][n+1].   A TLev sample is int64[l_lev][2][N]; an MKRLweSample int64[P+1][N] = a_0 .. a_{P-1}, b.
+ * ========================================================================================== */
+struct oracle_kms_ctx {
+    oracle_kms_params p;
+    const int64_t *gsw, *uni, *pk, *crs;
+    const int32_t *ksk;
+};
+oracle_kms_ctx *oracle_kms_ctx_create(const oracle_kms_params *p, const int64_t *gsw, const int64_t *uni, const int64_t *pk, const int64_t *crs,
+                                      const int32_t *ksk) {
+    oracle_kms_ctx *c = (oracle_kms_ctx *)calloc(1, sizeof(*c));
+    c->p = *p;
+    c->gsw = gsw, c->uni = uni, c->pk = pk, c->crs = crs, c->ksk = ksk;
+    return c;
+}
+void oracle_kms_ctx_destroy(oracle_kms_ctx *c) { free(c); }
+
+/* acc += sign * small (*) torus    (exact; the reference's transformed_mul / IntPolynomial * TorusPolynomial) */
+static void kms_mulacc(const int64_t *small, const int64_t *torus, int N, int64_t *acc, int sign, int use_schoolbook, int64_t *tmp) {
+    if (use_schoolbook) oracle_polymul_schoolbook64(small, torus, N, tmp);
+    else oracle_polymul_ntt64(small, torus, N, tmp);
+    for (int q = 0; q < N; q++) acc[q] = (int64_t)(sign > 0 ? (uint64_t)acc[q] + (uint64_t)tmp[q] : (uint64_t)acc[q] - (uint64_t)tmp[q]);
+}
+
+/* mk_ith_blind_rotate: TLev accumulator of party `party`      J/new_mk_internals.jl:210-225, mk_mux_rotate_new :177-182,
+ * tlev_trivial_int J/tlev.jl:37-45, tgsw_intern_mul J/tlev.jl:85-92 (tgsw_extern_mul per TLev sample, J/tgsw.jl:146-156) */
+void oracle_kms_tlev_rotate(const oracle_kms_ctx *c, int32_t party, const int32_t *bara, int64_t *lev, int use_schoolbook) {
+    const int N = c->p.N, n = c->p.n, lg = c->p.l_gsw, lv = c->p.l_lev, rows = 2 * lg;
+    int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(2 + rows + 2 + 1) * N);
+    int64_t *dig = tmp + 2 * (size_t)N, *ext = dig + (size_t)rows * N, *pr = ext + 2 * (size_t)N;
+    memset(lev, 0, sizeof(int64_t) * (size_t)lv * 2 * N);
+    for (int s = 0; s < lv; s++) lev[((size_t)s * 2 + 1) * N] = (int64_t)(1ull << (64 - (s + 1) * c->p.bg_lev)); /* body += 1 * gadget[s] */
+    for (int j = 0; j < n; j++) {
+        if (bara[j] == 0) continue;
+        const int64_t *key = c->gsw + (((size_t)party * n + j) * rows) * 2 * N;
+        for (int s = 0; s < lv; s++) {
+            int64_t *acc = lev + (size_t)s * 2 * N;
+            for (int m = 0; m < 2; m++) {
+                oracle_mul_by_monomial64(acc + (size_t)m * N, bara[j], N, tmp + (size_t)m * N);
+                for (int q = 0; q < N; q++) tmp[(size_t)m * N + q] = (int64_t)((uint64_t)tmp[(size_t)m * N + q] - (uint64_t)acc[(size_t)m * N + q]);
+                oracle_decompose64(tmp + (size_t)m * N, N, lg, c->p.bg_gsw, dig + (size_t)m * lg * N);
+            }
+            memset(ext, 0, sizeof(int64_t) * 2 * (size_t)N);
+            for (int r = 0; r < rows; r++)
+                for (int col = 0; col < 2; col++) kms_mulacc(dig + (size_t)r * N, key + ((size_t)r * 2 + col) * N, N, ext + (size_t)col * N, 1, use_schoolbook, pr);
+            for (int q = 0; q < 2 * N; q++) acc[q] = (int64_t)((uint64_t)acc[q] + (uint64_t)ext[q]);
+        }
+    }
+    free(tmp);
+}
+
+/* UniProduct_new      J/new_mk_internals.jl:85-127.  e, out: int64[P+1][N] */
+void oracle_kms_uniproduct(const oracle_kms_ctx *c, int32_t party, const int64_t *e, int64_t *out, int use_schoolbook) {
+    const int N = c->p.N, P = c->p.parties, lu = c->p.l_uni;
+    const int64_t *d = c->uni + (((size_t)party * 3 + 0) * lu) * N, *f0 = c->uni + (((size_t)party * 3 + 1) * lu) * N,
+                  *f1 = c->uni + (((size_t)party * 3 + 2) * lu) * N;
+    int64_t *dec = (int64_t *)malloc(sizeof(int64_t) * ((size_t)(P + 1) * lu + lu + 2) * N);
+    int64_t *dec_v = dec + (size_t)(P + 1) * lu * N, *v = dec_v + (size_t)lu * N, *pr = v + N;
+    for (int i = 0; i <= P; i++) oracle_decompose64(e + (size_t)i * N, N, lu, c->p.bg_uni, dec + (size_t)i * lu * N); /* i = P: dec_b */
+    memset(out, 0, sizeof(int64_t) * (size_t)(P + 1) * N);
+    memset(v, 0, sizeof(int64_t) * N);
+    for (int i = 0; i <= P; i++)
+        for (int l = 0; l < lu; l++) {
+            const int64_t *di = dec + ((size_t)i * lu + l) * N;
+            kms_mulacc(di, d + (size_t)l * N, N, out + (size_t)i * N, 1, use_schoolbook, pr); /* u_i (i < P), u0 (i = P) */
+            if (i < P) kms_mulacc(di, c->pk + ((size_t)i * lu + l) * N, N, v, 1, use_schoolbook, pr);
+            else kms_mulacc(di, c->crs + (size_t)l * N, N, v, -1, use_schoolbook, pr);
+        }
+    oracle_decompose64(v, N, lu, c->p.bg_uni, dec_v);
+    for (int l = 0; l < lu; l++) {
+        kms_mulacc(dec_v + (size_t)l * N, f0 + (size_t)l * N, N, out + (size_t)P * N, 1, use_schoolbook, pr);     /* bnew = u0 + w0 */
+        kms_mulacc(dec_v + (size_t)l * N, f1 + (size_t)l * N, N, out + (size_t)party * N, 1, use_schoolbook, pr); /* anew[party] += w1 */
+    }
+    free(dec);
+}
+
+/* mk_lev_rlwe_mul: accum <- f - UniProduct_new(e), (e, f) = tlev_extern_mul of accum's polynomials      J/new_mk_internals.jl:185-207,
+ * tlev_extern_mul J/tlev.jl:72-76 */
+void oracle_kms_lev_rlwe_mul(const oracle_kms_ctx *c, int32_t party, int64_t *accum, const int64_t *lev, int use_schoolbook) {
+    const int N = c->p.N, P = c->p.parties, lv = c->p.l_lev;
+    int64_t *e = (int64_t *)calloc((size_t)(3 * (P + 1) + lv + 1) * N, sizeof(int64_t));
+    int64_t *f = e + (size_t)(P + 1) * N, *up = f + (size_t)(P + 1) * N, *dec = up + (size_t)(P + 1) * N, *pr = dec + (size_t)lv * N;
+    for (int i = 0; i <= P; i++) {
+        if (i < P && i >= party) continue; /* only the parties before `party`, and b (i = P) */
+        oracle_decompose64(accum + (size_t)i * N, N, lv, c->p.bg_lev, dec);
+        for (int s = 0; s < lv; s++) {
+            kms_mulacc(dec + (size_t)s * N, lev + ((size_t)s * 2 + 0) * N, N, e + (size_t)i * N, 1, use_schoolbook, pr);
+            kms_mulacc(dec + (size_t)s * N, lev + ((size_t)s * 2 + 1) * N, N, f + (size_t)i * N, 1, use_schoolbook, pr);
+        }
+    }
+    oracle_kms_uniproduct(c, party, e, up, use_schoolbook);
+    for (size_t q = 0; q < (size_t)(P + 1) * N; q++) accum[q] = (int64_t)((uint64_t)f[q] - (uint64_t)up[q]);
+    free(e);
+}
+
+/* mk_bootstrap_wo_keyswitch_new (fast_boot = false): x int32[P*n+1] -> out int32[P*N+1]      J/new_mk_internals.jl:254-262,276-283,
+ * 303-314; extraction mk_rlwe_extract_sample_64 :295-300 */
+void oracle_kms_bootstrap_wo_keyswitch(const oracle_kms_ctx *c, int64_t mu, const int32_t *x, int32_t *out, int use_schoolbook) {
+    const int N = c->p.N, n = c->p.n, P = c->p.parties, lv = c->p.l_lev;
+    int32_t barb = oracle_modswitch(x[(size_t)n * P], N);
+    int64_t *accum = (int64_t *)calloc((size_t)(P + 1) * N + N + (size_t)lv * 2 * N, sizeof(int64_t));
+    int64_t *tv = accum + (size_t)(P + 1) * N, *lev = tv + N;
+    int32_t *bara = (int32_t *)malloc(sizeof(int32_t) * n);
+    for (int j = 0; j < N; j++) tv[j] = mu;
+    oracle_mul_by_monomial64(tv, -barb, N, accum + (size_t)P * N);
+    for (int p = 0; p < P; p++) {
+        for (int j = 0; j < n; j++) bara[j] = oracle_modswitch(x[(size_t)p * n + j], N);
+        oracle_kms_tlev_rotate(c, p, bara, lev, use_schoolbook);
+        oracle_kms_lev_rlwe_mul(c, p, accum, lev, use_schoolbook);
+    }
+    for (int p = 0; p < P; p++) {
+        const int64_t *a = accum + (size_t)p * N;
+        out[(size_t)p * N] = oracle_t64tot32(a[0]);
+        for (int j = 1; j < N; j++) out[(size_t)p * N + j] = oracle_t64tot32((int64_t)(0ull - (uint64_t)a[N - j]));
+    }
+    out[(size_t)P * N] = oracle_t64tot32(accum[(size_t)P * N]);
+    free(bara);
+    free(accum);
+}
+/* mk_keyswitch (party p switches its own extracted mask)      J/mk_internals.jl:714-728 */
+void oracle_kms_keyswitch(const oracle_kms_ctx *c, const int32_t *in, int32_t *out) {
+    const int N = c->p.N, n = c->p.n, P = c->p.parties, t = c->p.ks_t, bb = c->p.ks_basebit;
+    const size_t per_party = (size_t)N * t * ((1 << bb) - 1) * ((size_t)n + 1);
+    int32_t *part = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    uint32_t b = (uint32_t)in[(size_t)P * N];
+    for (int p = 0; p < P; p++) {
+        keyswitch_with(c->ksk + (size_t)p * per_party, N, n, t, bb, in + (size_t)p * N, 0, part);
+        memcpy(out + (size_t)p * n, part, sizeof(int32_t) * n);
+        b += (uint32_t)part[n];
+    }
+    out[(size_t)n * P] = (int32_t)b;
+    free(part);
+}
+/* mk_gate_nand_new (J/new_mk_gates.jl:1-7) and, on the same bootstrap, the other two-input linear prologues of J/gates.jl */
+int oracle_kms_gates(const oracle_kms_ctx *c, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count, int use_schoolbook) {
+    const int n = c->p.n, N = c->p.N, P = c->p.parties;
+    const size_t rec = (size_t)n * P + 1;
+    lin_t L;
+    if (op == OR_GATE_MUX || op == OR_GATE_NOT || op == OR_GATE_COPY || gate_lin(op, 0, &L) != 0) return -1;
+    int32_t *res = (int32_t *)malloc(sizeof(int32_t) * count * rec);
+#pragma omp parallel for schedule(dynamic)
+    for (long g = 0; g < (long)count; g++) {
+        int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (rec + (size_t)P * N + 1)), *u = tmp + rec;
+        const int32_t *x = in0 + g * rec, *y = in1 + g * rec;
+        for (size_t q = 0; q < rec; q++) tmp[q] = (int32_t)((uint32_t)L.cx * (uint32_t)x[q] + (uint32_t)L.cy * (uint32_t)y[q]);
+        tmp[rec - 1] = (int32_t)((uint32_t)tmp[rec - 1] + (uint32_t)L.cb);
+        oracle_kms_bootstrap_wo_keyswitch(c, (int64_t)1 << 61, tmp, u, use_schoolbook); /* encode_message64(1, 8) */
+        oracle_kms_keyswitch(c, u, res + g * rec);
+        free(tmp);
+    }
+    memcpy(out, res, sizeof(int32_t) * count * rec);
+    free(res);
+    return 0;
+}

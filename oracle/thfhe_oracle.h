@@ -129,6 +129,25 @@ void oracle_tlwe_from_lwe(const int32_t *lwe /*[N+1]*/, int32_t N, int32_t *tlwe
 void oracle_partial_decrypt(const int32_t *key_share, const int32_t *tlwe_a, const int32_t *noise, int32_t N, int32_t *partial);
 int32_t oracle_final_decrypt(const int32_t *tlwe_b, const int32_t *partials /*[t][N]*/, int32_t t, int32_t N, int32_t *result);
 
+/* ---- KMS multi-key scheme (mk_bootstrap_new / mk_gate_nand_new)   3-gen-mk-tfhe/src/new_mk_internals.jl, tlev.jl ---- */
+typedef struct {
+    int32_t n, N, parties;
+    int32_t l_gsw, bg_gsw; /* per-party TGSW blind rotation of the TLev accumulator */
+    int32_t l_lev, bg_lev; /* the TLev accumulator */
+    int32_t l_uni, bg_uni; /* uni-encryption / public keys / shared key */
+    int32_t ks_t, ks_basebit;
+} oracle_kms_params;
+typedef struct oracle_kms_ctx oracle_kms_ctx;
+oracle_kms_ctx *oracle_kms_ctx_create(const oracle_kms_params *p, const int64_t *gsw, const int64_t *uni, const int64_t *pk, const int64_t *crs,
+                                      const int32_t *ksk);
+void oracle_kms_ctx_destroy(oracle_kms_ctx *c);
+void oracle_kms_tlev_rotate(const oracle_kms_ctx *c, int32_t party, const int32_t *bara, int64_t *lev, int use_schoolbook);
+void oracle_kms_uniproduct(const oracle_kms_ctx *c, int32_t party, const int64_t *e, int64_t *out, int use_schoolbook);
+void oracle_kms_lev_rlwe_mul(const oracle_kms_ctx *c, int32_t party, int64_t *accum, const int64_t *lev, int use_schoolbook);
+void oracle_kms_bootstrap_wo_keyswitch(const oracle_kms_ctx *c, int64_t mu, const int32_t *x, int32_t *out, int use_schoolbook);
+void oracle_kms_keyswitch(const oracle_kms_ctx *c, const int32_t *in, int32_t *out);
+int oracle_kms_gates(const oracle_kms_ctx *c, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count, int use_schoolbook);
+
 int oracle_max_threads(void);
 void oracle_set_threads(int n); /* OpenMP team size for the batch entry points */
 

@@ -127,6 +127,14 @@ def lib():
         "oracle_tlwe_from_lwe": (None, [i32p, C.c_int32, i32p, i32p]),
         "oracle_partial_decrypt": (None, [i32p, i32p, i32p, C.c_int32, i32p]),
         "oracle_final_decrypt": (C.c_int32, [i32p, i32p, C.c_int32, C.c_int32, i32p]),
+        "oracle_kms_ctx_create": (vp, [C.c_void_p, i64p, i64p, i64p, i64p, i32p]),
+        "oracle_kms_ctx_destroy": (None, [vp]),
+        "oracle_kms_tlev_rotate": (None, [vp, C.c_int32, i32p, i64p, C.c_int]),
+        "oracle_kms_uniproduct": (None, [vp, C.c_int32, i64p, i64p, C.c_int]),
+        "oracle_kms_lev_rlwe_mul": (None, [vp, C.c_int32, i64p, i64p, C.c_int]),
+        "oracle_kms_bootstrap_wo_keyswitch": (None, [vp, C.c_int64, i32p, i32p, C.c_int]),
+        "oracle_kms_keyswitch": (None, [vp, i32p, i32p]),
+        "oracle_kms_gates": (C.c_int, [vp, C.c_int, i32p, i32p, i32p, C.c_size_t, C.c_int]),
         "oracle_max_threads": (C.c_int, []),
         "oracle_set_threads": (None, [C.c_int]),
     }
@@ -338,6 +346,54 @@ class Oracle:
         acc = np.ascontiguousarray(acc, np.int32).copy()
         lib().oracle_mux_rotate(self.h, i, barai, p32(acc), int(schoolbook))
         return acc
+
+
+class KmsParams(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in ("n", "N", "parties", "l_gsw", "bg_gsw", "l_lev", "bg_lev", "l_uni", "bg_uni", "ks_t", "ks_basebit")]
+
+
+class KMSOracle:
+    """KMS scheme (mk_bootstrap_new) oracle context over given key tables (layouts: thfhe_oracle.c, section KMS)."""
+
+    def __init__(self, params, gsw, uni, pk, crs, ksk):
+        self.params = p = KmsParams(**{f: getattr(params, f) for f, _ in KmsParams._fields_})
+        self.tabs = [np.ascontiguousarray(a, np.int64) for a in (gsw, uni, pk, crs)] + [np.ascontiguousarray(ksk, np.int32)]
+        assert self.tabs[0].shape == (p.parties, p.n, 2 * p.l_gsw, 2, p.N) and self.tabs[1].shape == (p.parties, 3, p.l_uni, p.N)
+        self.h = lib().oracle_kms_ctx_create(C.byref(p), *[p64(a) for a in self.tabs[:4]], p32(self.tabs[4]))
+        self.words = p.parties * p.n + 1
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_kms_ctx_destroy(self.h)
+            self.h = None
+
+    def gates(self, op, in0, in1, schoolbook=False):
+        in0, in1 = np.ascontiguousarray(in0, np.int32), np.ascontiguousarray(in1, np.int32)
+        out = np.zeros_like(in0)
+        assert lib().oracle_kms_gates(self.h, op, p32(in0), p32(in1), p32(out), in0.shape[0], int(schoolbook)) == 0
+        return out
+
+    def tlev_rotate(self, party, bara, schoolbook=False):
+        p = self.params
+        lev = np.zeros((p.l_lev, 2, p.N), np.int64)
+        lib().oracle_kms_tlev_rotate(self.h, party, p32(np.ascontiguousarray(bara, np.int32)), p64(lev), int(schoolbook))
+        return lev
+
+    def lev_rlwe_mul(self, party, accum, lev, schoolbook=False):
+        accum = np.ascontiguousarray(accum, np.int64).copy()
+        lib().oracle_kms_lev_rlwe_mul(self.h, party, p64(accum), p64(np.ascontiguousarray(lev, np.int64)), int(schoolbook))
+        return accum
+
+    def bootstrap_wo_keyswitch(self, x, mu=1 << 61, schoolbook=False):
+        p = self.params
+        out = np.zeros(p.parties * p.N + 1, np.int32)
+        lib().oracle_kms_bootstrap_wo_keyswitch(self.h, mu, p32(np.ascontiguousarray(x, np.int32)), p32(out), int(schoolbook))
+        return out
+
+    def keyswitch(self, u):
+        out = np.zeros(self.words, np.int32)
+        lib().oracle_kms_keyswitch(self.h, p32(np.ascontiguousarray(u, np.int32)), p32(out))
+        return out
 
 
 class MKOracle:

@@ -1,0 +1,67 @@
+"""KMS multi-key scheme on the GPU (mk_gate_nand_new / mk_bootstrap_new, 3-gen-mk-tfhe/src/new_mk_gates.jl:1-7, new_mk_internals.jl):
+the fused TLev blind-rotation kernel, the relinearisation products (thfhe_pm_mac) and the key switch against the CPU oracle, bit for bit,
+on the gadgets of the reference's 2-, 4- and 8-party sets (mk_api.jl:12-20, 64-72, 120-128; ring degree 2048, Torus64) with a reduced LWE
+dimension.  Ciphertext parity with the reference itself is UNPINNED (no KMS fixtures, Julia RNG); the pin is the reference's own
+multi-key test pattern, the NAND truth table (test/runtests.jl:62-102)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(O, name, n, parties=None, seed=7):
+    import thfhe
+    from thfhe import keygen, kms
+    over = dict(n=n)
+    if parties:
+        over["parties"] = parties
+    p = thfhe.make_kms_params(name, **over)
+    K = keygen.KMSSecretKeySet(p, seed=seed)
+    orc = O.KMSOracle(p, K.gsw, K.uni, K.pk, K.crs, K.ksk)
+    ck = kms.KMSCloudKey(p, K.gsw, K.uni, K.pk, K.crs, K.ksk, device=0)
+    return p, K, orc, ck
+
+
+@pytest.mark.parametrize("name,n,parties", [("KMS2", 12, None), ("KMS2-fast", 5, None), ("KMS4", 6, None), ("KMS8", 4, 3)])
+def test_kms_pieces_and_gates_bit_exact(O, name, n, parties):
+    # KMS2: l_gsw = 3, Bgbit 13 -> two-part digits, 12 row parts (two LDS batches); KMS4: l_gsw = 5, Bgbit 8 -> 10 row parts;
+    # KMS8 gadgets (l_gsw = 4, Bgbit 11 -> 16 row parts, three batches; l_lev = 3; l_uni = 8) on three parties
+    from thfhe import kms
+    p, K, orc, ck = setup(O, name, n, parties)
+    a, b = np.array([0, 0, 1, 1, 1]), np.array([0, 1, 0, 1, 1])
+    ca, cb = K.encrypt(a, 21), K.encrypt(b, 22)
+    # mk_ith_blind_rotate: the TLev accumulator of every party
+    bar = kms.modswitch(ca, p.N)
+    for party in range(p.parties):
+        lev = ck.tlev_rotate(party, bar[:2, party * n:(party + 1) * n])
+        for g in range(2):
+            assert np.array_equal(lev[g], orc.tlev_rotate(party, bar[g, party * n:(party + 1) * n])), (name, party, g)
+    # mk_lev_rlwe_mul on a random accumulator
+    rng = np.random.default_rng(3)
+    acc = rng.integers(-2**63, 2**63, size=(2, p.parties + 1, p.N), dtype=np.int64)
+    party = p.parties - 1
+    got = ck.lev_rlwe_mul(party, acc, lev)
+    for g in range(2):
+        assert np.array_equal(got[g], orc.lev_rlwe_mul(party, acc[g], lev[g])), (name, g)
+    # whole bootstrap and the gate
+    u = ck.bootstrap_wo_keyswitch(ca[:2])
+    assert np.array_equal(u[0], orc.bootstrap_wo_keyswitch(ca[0]))
+    assert np.array_equal(ck.keyswitch(u), np.stack([orc.keyswitch(r) for r in u]))
+    out = kms.mk_gate_nand_new(ck, ca, cb)
+    assert np.array_equal(out, orc.gates(O.NAND, ca, cb))
+    assert np.array_equal(K.decrypt(out), ~(a.astype(bool) & b.astype(bool)))
+    assert np.array_equal(ck.gates(O.XOR, ca, cb), orc.gates(O.XOR, ca, cb))
+    ck.close()
+
+
+def test_kms2_truth_table_larger_n(O):
+    # the reference's NAND test pattern with a larger LWE dimension (n = 96 of 560): decrypt-level check, two gates against the oracle
+    from thfhe import kms
+    p, K, orc, ck = setup(O, "KMS2", 96, seed=9)
+    a, b = np.array([0, 0, 1, 1]), np.array([0, 1, 0, 1])
+    ca, cb = K.encrypt(a, 31), K.encrypt(b, 32)
+    out = kms.mk_gate_nand_new(ck, ca, cb)
+    assert np.array_equal(K.decrypt(out), ~(a.astype(bool) & b.astype(bool)))
+    assert np.abs(np.abs(K.phase(out).astype(np.float64) / 2.0**32) - 0.125).max() < 0.06
+    assert np.array_equal(out[:2], orc.gates(O.NAND, ca[:2], cb[:2]))
+    ck.close()

@@ -1,0 +1,355 @@
+// thfhe_kms.hip -- the KMS multi-key scheme (mk_bootstrap_new / mk_gate_nand_new) on gfx950: device side.
+//   reference: 3-gen-mk-tfhe/src/new_mk_internals.jl (mk_ith_blind_rotate :210-225, mk_mux_rotate_new :177-182, mk_lev_rlwe_mul :185-207,
+//   UniProduct_new :85-127, mk_bootstrap_new :303-325), tlev.jl (TLev accumulators), mk_internals.jl:714-728 (mk_keyswitch).
+//
+// Where the time goes: per party, the TLev accumulator (l_lev RLWE samples over a Torus64 ring of degree 2048) is blind-rotated by the
+// party's n TGSW-encrypted key bits -- n x l_lev CMuxes with 2 l_gsw digit rows each; everything after it (tlev_extern_mul, UniProduct_new:
+// a few dozen polynomial products per party and gate) is less than 1 % of the arithmetic and goes through thfhe_pm_mac (thfhe_polymac.hip)
+// under the host layer thfhe/kms.py.  This file holds
+//   kms_tlev_rotate_kernel   one 512-thread workgroup per (gate, TLev sample): the N = 2048 cooperative structure of thfhe_mk.hip
+//                            (digit rows transformed by up to six waves, (column, limb) multiply-accumulate + inverse on all eight,
+//                            key chunks requested two ahead), generalised to what the reference's KMS sets need:
+//                            * digits taken from the full 64-bit word (l_gsw Bgbit = 39 .. 48 bits);
+//                            * digits wider than 10 bit are cut in two balanced parts d = d_lo + 2^w d_hi; the second part multiplies
+//                              the key row shifted left by w bits (a second table, built once), so both parts accumulate into ONE set of
+//                              spectra and every limb sum stays inside the FP64 exactness bound (12 x 2048 x 2^6 x 2^15 = 2^35.6);
+//                            * any number of row parts: they pass through the LDS in batches of six.
+//   thfhe_kms_keyswitch      mk_keyswitch: party p key-switches its own extracted mask (thfhe_mk_shared.h).
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/thfhe_hip.h"
+#include "thfhe_common.h"
+#include "thfhe_lane.h"
+#include "thfhe_mk_shared.h"
+
+using namespace thfhe;
+
+namespace {
+
+THFHE_STAMP_STORAGE
+
+__device__ __forceinline__ void kms_pin() { asm volatile("" ::: "memory"); }
+
+// torus polynomials int64[npolys][2048] -> limb spectra [poly][limb h][half][512], scaled by 1/1024 (one wave per (poly, limb))
+__global__ __launch_bounds__(256) void kms_key_transform_kernel(const int64_t *__restrict__ polys, long npolys, const cplx *__restrict__ tw,
+                                                                 cplx *__restrict__ spec) {
+    __shared__ cplx sT1[2][512];
+    __shared__ cplx sX[4][512];
+    for (int t = threadIdx.x; t < 1024; t += 256) (&sT1[0][0])[t] = tw[t];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const W64 w64{tw[1024 + 1 * 8 + (lane & 7)]};
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= npolys * 4) return;
+    cplx z[16], y0[8], y1[8];
+    key_limbs64_to_z16(lane, polys + (item >> 2) * 2048, (int)(item & 3), z);
+    split2048(z, y0, y1);
+    wave_fft_fwd_t<1>(lane, y0, sX[wave], sT1[0], w64);
+    wave_fft_fwd_t<5>(lane, y1, sX[wave], sT1[1], w64);
+    cplx *dst = spec + (size_t)item * 1024;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        dst[m * 64 + lane] = cplx{y0[m].re * (1.0 / 1024), y0[m].im * (1.0 / 1024)};
+        dst[512 + m * 64 + lane] = cplx{y1[m].re * (1.0 / 1024), y1[m].im * (1.0 / 1024)};
+    }
+}
+
+struct KmsBRArgs {
+    const cplx *bk;       // the party's key spectra [j][row part][column o][limb h][half][512]
+    const cplx *tw;
+    const int32_t *bara;  // [gates][n]: the party's mod-switched mask words
+    int64_t *acc_out;     // [gates * l_lev][2][2048]: TLev sample s of gate g at job g * l_lev + s
+    long jobs;
+    int n, lg, bg, parts, lo_bits, l_lev, bg_lev;
+};
+
+__global__ __launch_bounds__(512, 2) void kms_tlev_rotate_kernel(KmsBRArgs a) {
+    constexpr int BATCH = 6;  // row parts whose spectra sit in the LDS at the same time (16 KiB each)
+    __shared__ cplx sT1[2][512];
+    __shared__ int64_t sAcc[4096];
+    __shared__ cplx sSpec[BATCH * 1024];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    for (int t = threadIdx.x; t < 1024; t += 512) (&sT1[0][0])[t] = a.tw[t];
+    const W64 w64{a.tw[1024 + 1 * 8 + (lane & 7)]};
+    const long job = blockIdx.x;
+    const long gate = job / a.l_lev;
+    const int sample = (int)(job % a.l_lev);
+    const int32_t *bara = a.bara + gate * a.n;
+    const int lg = a.lg, bg = a.bg, parts = a.parts, lo_bits = a.lo_bits;
+    const int RP = 2 * lg * parts;
+    uint64_t offset = 0;
+    for (int p = 1; p <= lg; p++) offset += (1ull << (bg - 1)) << (64 - p * bg);
+    // tlev_trivial_int(levpar, lwepar, 1): mask 0, body = gadget value of level `sample` on the constant coefficient     (J/tlev.jl:37-66)
+    for (int q = threadIdx.x; q < 4096; q += 512) sAcc[q] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) sAcc[2048] = (int64_t)(1ull << (64 - (sample + 1) * a.bg_lev));
+    __syncthreads();
+    const int o = wave >> 2, h = wave & 3;
+    unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc) + o * 2048;
+    auto chunk = [&](int step, int rp, int half) { return a.bk + (((((size_t)step * RP + rp) * 2 + o) * 4 + h) * 2 + half) * 512; };
+
+    int i = 0;
+    while (i < a.n && bara[i] == 0) i++;
+    while (i < a.n) {
+        const int a2n = bara[i] & 4095;
+        int inext = i + 1;
+        while (inext < a.n && bara[inext] == 0) inext++;
+        cplx S0[8], S1[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) S0[m] = S1[m] = cplx{0.0, 0.0};
+        for (int b0 = 0; b0 < RP; b0 += BATCH) {
+            const int nb = RP - b0 < BATCH ? RP - b0 : BATCH;
+            if (wave < nb) {
+                const int rp = b0 + wave, r = rp / parts, part = rp % parts;
+                const int64_t *ap = sAcc + (r / lg) * 2048;
+                const int shift = 64 - ((r % lg) + 1) * bg;
+                const uint64_t mask = (1ull << bg) - 1ull;
+                const int32_t half_bg = 1 << (bg - 1), half_lo = 1 << (lo_bits - 1), mask_lo = (1 << lo_bits) - 1;
+                constexpr double R = 0.70710678118654752440;
+                cplx y0[8], y1[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    double d[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint64_t v = rot_minus_self64_n<2048>(ap, lane + 64 * m + 512 * q, a2n) + offset;
+                        int32_t dg = (int32_t)((v >> shift) & mask) - half_bg;                     // decompose, J/tgsw.jl:112-138 (64-bit words)
+                        if (parts == 2) {
+                            const int32_t lo = ((dg + half_lo) & mask_lo) - half_lo;               // balanced low part
+                            dg = part ? (dg - lo) >> lo_bits : lo;
+                        }
+                        d[q] = (double)dg;
+                    }
+                    const cplx w{(d[1] - d[3]) * R, (d[1] + d[3]) * R};
+                    y0[m] = cplx{d[0] + w.re, d[2] + w.im};
+                    y1[m] = cplx{d[0] - w.re, d[2] - w.im};
+                    if (m & 1) kms_pin();   // at most 8 of the 32 rotated 64-bit reads in flight: the partial spectra keep 64 registers busy here
+                }
+                cplx *xb = sSpec + wave * 1024;
+                wave_fft_fwd_t<1>(lane, y0, xb, sT1[0], w64);
+                wave_fft_fwd_t<5>(lane, y1, xb, sT1[1], w64);
+                wave_sync();
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    xb[m * 64 + lane] = y0[m];
+                    xb[512 + m * 64 + lane] = y1[m];
+                }
+            }
+            // key chunks of this batch: requested after the transforms (the partial spectra S0 / S1 stay alive across the batches of a step,
+            // so there are no registers for chunks in flight under the transforms), then one row part ahead inside the batch
+            cplx bA[8], bB[8];
+            load8(lane, bA, chunk(i, b0, 0));
+            load8(lane, bB, chunk(i, b0, 1));
+            __syncthreads();  // this batch's spectra published (and, for the first batch, every rotated read of the accumulator done)
+            for (int q = 0; q < nb; q++) {
+                const int rp = b0 + q;
+                const int rn = q + 1 < nb ? rp + 1 : rp;   // the last row part of a batch re-requests itself (unconditional loads)
+                cplx z[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) z[m] = sSpec[q * 1024 + m * 64 + lane];
+                mac8r(S0, z, bA);
+                kms_pin();
+                load8(lane, bA, chunk(i, rn, 0));
+                kms_pin();
+#pragma unroll
+                for (int m = 0; m < 8; m++) z[m] = sSpec[q * 1024 + 512 + m * 64 + lane];
+                mac8r(S1, z, bB);
+                kms_pin();
+                load8(lane, bB, chunk(i, rn, 1));
+                kms_pin();
+            }
+            __syncthreads();  // spectra consumed: the area is free for the next batch / the inverse transforms
+        }
+        {
+            cplx *xb = sSpec + wave * 512;
+            wave_fft_inv_t<1>(lane, S0, xb, sT1[0], w64);
+            wave_fft_inv_t<5>(lane, S1, xb, sT1[1], w64);
+            cplx lo[8], hi[8];
+            merge2048(S0, S1, lo, hi);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int q = lane + 64 * m;
+                atomicAdd(accu + q, (unsigned long long)round_i64(lo[m].re) << (16 * h));
+                atomicAdd(accu + q + 512, (unsigned long long)round_i64(hi[m].re) << (16 * h));
+                atomicAdd(accu + q + 1024, (unsigned long long)round_i64(lo[m].im) << (16 * h));
+                atomicAdd(accu + q + 1536, (unsigned long long)round_i64(hi[m].im) << (16 * h));
+            }
+        }
+        __syncthreads();  // accumulator updated and scratch free before the next rotation
+        i = inext;
+    }
+    for (int q = threadIdx.x; q < 4096; q += 512) a.acc_out[job * 4096 + q] = sAcc[q];
+}
+
+}  // namespace
+
+struct thfhe_kms_ctx {
+    thfhe_kms_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    cplx *d_tw = nullptr;
+    cplx *d_bk = nullptr;       // [party][j][row part][o][h][half][512]
+    int32_t *d_ksk = nullptr;
+    int parts = 1, lo_bits = 1, row_words = 0;
+    size_t party_stride = 0;    // complex elements per party in d_bk
+    void *d_buf[3] = {nullptr, nullptr, nullptr};
+    size_t cap[3] = {0, 0, 0};
+    std::mutex mu;
+};
+
+namespace {
+int kms_ensure(thfhe_kms_ctx *c, int slot, size_t bytes) {
+    if (bytes <= c->cap[slot]) return THFHE_OK;
+    (void)hipFree(c->d_buf[slot]);
+    c->d_buf[slot] = nullptr;
+    c->cap[slot] = 0;
+    THFHE_HIP(hipMalloc(&c->d_buf[slot], bytes));
+    c->cap[slot] = bytes;
+    return THFHE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int thfhe_kms_ctx_create(const thfhe_kms_params *p, const int64_t *gsw, const int32_t *ksk, int device, thfhe_kms_ctx **out) {
+    if (!p || !gsw || !ksk || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    *out = nullptr;
+    if (p->N != 2048) return thfhe_fail(THFHE_E_UNSUPPORTED, "the KMS scheme is implemented for its reference ring degree N = 2048 (Torus64)");
+    if (p->parties < 1 || p->n < 1 || p->n > 767) return thfhe_fail(THFHE_E_UNSUPPORTED, "need parties >= 1, 1 <= n <= 767");
+    if (p->l_gsw < 1 || p->l_gsw > 8 || p->bg_gsw < 2 || p->bg_gsw > 14 || p->l_gsw * p->bg_gsw > 64)
+        return thfhe_fail(THFHE_E_UNSUPPORTED, "gsw gadget: need 1 <= l <= 8, 2 <= Bgbit <= 14, l * Bgbit <= 64");
+    if (p->l_lev < 1 || p->l_lev > 8 || p->bg_lev < 1 || p->l_lev * p->bg_lev > 64) return thfhe_fail(THFHE_E_UNSUPPORTED, "bad lev gadget");
+    if (p->ks_t < 1 || p->ks_basebit < 1 || p->ks_t * p->ks_basebit > 31) return thfhe_fail(THFHE_E_INVALID, "bad key-switch parameters");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return thfhe_fail(THFHE_E_NO_DEVICE, "no usable HIP device (this library has no CPU fallback)");
+    THFHE_HIP(hipSetDevice(device));
+    thfhe_kms_ctx *c = new (std::nothrow) thfhe_kms_ctx;
+    if (!c) return thfhe_fail(THFHE_E_NOMEM, "out of host memory");
+    c->p = *p;
+    c->device = device;
+    c->parts = p->bg_gsw > 10 ? 2 : 1;          // digits beyond 10 bit are cut in two (FP64 exactness bound)
+    c->lo_bits = (p->bg_gsw + 1) / 2;
+    c->row_words = 128 * ((p->n + 1 + 127) / 128);
+    const int RP = 2 * p->l_gsw * c->parts, N = 2048;
+    // exactness: RP * N * 2^(part width - 1) * 2^15 must stay below 2^37 (N = 2048 bound of DESIGN.md section 4.3)
+    const int part_bits = c->parts == 2 ? c->lo_bits : p->bg_gsw;
+    if ((double)RP * N * (double)(1 << (part_bits - 1)) * 32768.0 > 137438953472.0 /* 2^37 */) {
+        delete c;
+        return thfhe_fail(THFHE_E_UNSUPPORTED, "gsw gadget outside the FP64 exactness bound of the N = 2048 transform");
+    }
+    int64_t *d_coeff = nullptr;
+    int32_t *d_raw = nullptr;
+    auto fail = [&](int code) {
+        (void)hipFree(d_coeff);
+        (void)hipFree(d_raw);
+        thfhe_kms_ctx_destroy(c);
+        return code;
+    };
+#define CK(expr)                                                      \
+    do {                                                              \
+        hipError_t e_ = (expr);                                       \
+        if (e_ != hipSuccess) return fail(thfhe_fail_hip(e_, #expr)); \
+    } while (0)
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    std::vector<cplx> tw(1088), unused(512);
+    make_twiddles_2048(tw.data(), tw.data() + 512);
+    make_twiddles_1024(unused.data(), tw.data() + 1024);
+    CK(hipMalloc(&c->d_tw, tw.size() * sizeof(cplx)));
+    CK(hipMemcpyAsync(c->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
+    // key table: per party and key bit the 2 l rows x 2 columns of the TGSW sample; with two-part digits every row is followed by its copy
+    // shifted left by lo_bits (wrapping): d (*) K = d_lo (*) K + d_hi (*) (K << lo_bits)
+    const size_t polys_per_party = (size_t)p->n * RP * 2;
+    c->party_stride = polys_per_party * 4 * 1024;
+    CK(hipMalloc(&c->d_bk, (size_t)p->parties * c->party_stride * sizeof(cplx)));
+    CK(hipMalloc(&d_coeff, polys_per_party * N * sizeof(int64_t)));
+    std::vector<int64_t> host(polys_per_party * N);
+    for (int q = 0; q < p->parties; q++) {
+        for (int j = 0; j < p->n; j++)
+            for (int r = 0; r < 2 * p->l_gsw; r++)
+                for (int part = 0; part < c->parts; part++)
+                    for (int col = 0; col < 2; col++) {
+                        const int64_t *src = gsw + ((((size_t)q * p->n + j) * 2 * p->l_gsw + r) * 2 + col) * N;
+                        int64_t *dst = host.data() + ((((size_t)j * RP + (size_t)r * c->parts + part) * 2) + col) * N;
+                        const int sh = part * c->lo_bits;
+                        for (int t = 0; t < N; t++) dst[t] = (int64_t)((uint64_t)src[t] << sh);
+                    }
+        CK(hipMemcpyAsync(d_coeff, host.data(), host.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(kms_key_transform_kernel, dim3((unsigned)((polys_per_party * 4 + 3) / 4)), dim3(256), 0, c->stream, d_coeff, (long)polys_per_party,
+                           c->d_tw, c->d_bk + (size_t)q * c->party_stride);
+        CK(hipGetLastError());
+        CK(hipStreamSynchronize(c->stream));   // `host` is reused for the next party
+    }
+    const long rows = (long)p->parties * N * p->ks_t * ((1 << p->ks_basebit) - 1);
+    CK(hipMalloc(&d_raw, (size_t)rows * (p->n + 1) * sizeof(int32_t)));
+    CK(hipMemcpyAsync(d_raw, ksk, (size_t)rows * (p->n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    CK(hipMalloc(&c->d_ksk, (size_t)rows * c->row_words * sizeof(int32_t)));
+    hipLaunchKernelGGL(mk_ksk_pad_kernel, dim3((unsigned)rows), dim3(256), 0, c->stream, d_raw, rows, p->n, c->row_words, c->d_ksk);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_coeff);
+    (void)hipFree(d_raw);
+#undef CK
+    *out = c;
+    return THFHE_OK;
+}
+
+void thfhe_kms_ctx_destroy(thfhe_kms_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_tw);
+    (void)hipFree(c->d_bk);
+    (void)hipFree(c->d_ksk);
+    for (auto &q : c->d_buf) (void)hipFree(q);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int thfhe_kms_tlev_rotate(thfhe_kms_ctx *c, int party, const int32_t *bara, int64_t *lev, size_t count) {
+    if (!c || !bara || !lev) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (party < 0 || party >= c->p.parties) return thfhe_fail(THFHE_E_INVALID, "party out of range");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t jobs = count * c->p.l_lev;
+    int rc = kms_ensure(c, 0, count * c->p.n * sizeof(int32_t));
+    if (!rc) rc = kms_ensure(c, 1, jobs * 4096 * sizeof(int64_t));
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(c->d_buf[0], bara, count * c->p.n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    KmsBRArgs a{c->d_bk + (size_t)party * c->party_stride, c->d_tw, (const int32_t *)c->d_buf[0], (int64_t *)c->d_buf[1], (long)jobs,
+                c->p.n, c->p.l_gsw, c->p.bg_gsw, c->parts, c->lo_bits, c->p.l_lev, c->p.bg_lev};
+    hipLaunchKernelGGL(kms_tlev_rotate_kernel, dim3((unsigned)jobs), dim3(512), 0, c->stream, a);
+    THFHE_HIP(hipGetLastError());
+    THFHE_HIP(hipMemcpyAsync(lev, c->d_buf[1], jobs * 4096 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+int thfhe_kms_keyswitch(thfhe_kms_ctx *c, const int32_t *u, int32_t *out, size_t count) {
+    if (!c || !u || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const int P = c->p.parties, N = c->p.N, n = c->p.n;
+    const size_t in_words = count * ((size_t)P * N + 1), out_words = count * ((size_t)P * n + 1);
+    int rc = kms_ensure(c, 1, in_words * sizeof(int32_t));
+    if (!rc) rc = kms_ensure(c, 2, out_words * sizeof(int32_t));
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(c->d_buf[1], u, in_words * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipMemsetAsync(c->d_buf[2], 0, out_words * sizeof(int32_t), c->stream));
+    MKKSArgs k{c->d_ksk, (const int32_t *)c->d_buf[1], (int32_t *)c->d_buf[2], (long)count, n, c->p.ks_t, c->p.ks_basebit, P, c->row_words, N, P * N + 1, N};
+    const int nsplit = count <= 64 ? 8 : 2;
+    hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)count, (unsigned)P, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
+    THFHE_HIP(hipGetLastError());
+    THFHE_HIP(hipMemcpyAsync(out, c->d_buf[2], out_words * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+}  // extern "C"

@@ -52,6 +52,30 @@ PARAM_SETS = {
 }
 
 
+class KmsParams(C.Structure):
+    """thfhe_kms_params (include/thfhe_hip.h): the KMS scheme (mk_bootstrap_new) has three gadget families -- gsw (per-party TGSW blind
+    rotation of the TLev accumulator), lev (the TLev accumulator), uni (uni-encryption / public keys) -- on a Torus64 ring."""
+    _fields_ = [(f, C.c_int32) for f in ("n", "N", "parties", "l_gsw", "bg_gsw", "l_lev", "bg_lev", "l_uni", "bg_uni", "ks_t", "ks_basebit")]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+# mktfhe_parameters_{2,4,8}party_new and _fast, mk_api.jl:12-30, 64-82, 120-138 (noise: lwe / ks 3.05e-5, gsw / uni 4.63e-18)
+KMS_PARAM_SETS = {
+    "KMS2": dict(n=560, N=2048, parties=2, l_gsw=3, bg_gsw=13, l_lev=2, bg_lev=7, l_uni=2, bg_uni=13, ks_t=8, ks_basebit=2),
+    "KMS2-fast": dict(n=560, N=2048, parties=2, l_gsw=3, bg_gsw=13, l_lev=2, bg_lev=7, l_uni=3, bg_uni=10, ks_t=8, ks_basebit=2),
+    "KMS4": dict(n=560, N=2048, parties=4, l_gsw=5, bg_gsw=8, l_lev=2, bg_lev=8, l_uni=5, bg_uni=8, ks_t=8, ks_basebit=2),
+    "KMS8": dict(n=560, N=2048, parties=8, l_gsw=4, bg_gsw=11, l_lev=3, bg_lev=6, l_uni=8, bg_uni=4, ks_t=8, ks_basebit=2),
+}
+
+
+def make_kms_params(name=None, **kw):
+    d = dict(KMS_PARAM_SETS[name]) if name else {}
+    d.update(kw)
+    return KmsParams(**d)
+
+
 def make_params(name=None, **kw):
     d = dict(PARAM_SETS[name]) if name else {}
     d.update(kw)
@@ -96,6 +120,10 @@ SIGNATURES = {
     "thfhe_tlwe_from_lwe": (C.c_int, [_vp, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_partial_decrypt": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_final_decrypt": (C.c_int, [_vp, _i32p, _i32p, C.c_int, _i32p, _i32p, C.c_size_t]),
+    "thfhe_kms_ctx_create": (C.c_int, [_vp, _i64p, _i32p, C.c_int, C.POINTER(_vp)]),
+    "thfhe_kms_ctx_destroy": (None, [_vp]),
+    "thfhe_kms_tlev_rotate": (C.c_int, [_vp, C.c_int, _i32p, _i64p, C.c_size_t]),
+    "thfhe_kms_keyswitch": (C.c_int, [_vp, _i32p, _i32p, C.c_size_t]),
     "thfhe_pm_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "thfhe_pm_ctx_destroy": (None, [_vp]),
     "thfhe_pm_mac": (C.c_int, [_vp, _i32p, C.c_size_t, _vp, C.c_size_t, _i32p, C.c_size_t, _vp, _vp, C.c_size_t]),

@@ -333,6 +333,57 @@ class CCSSecretKeySet:
     decrypt = MKSecretKeySet.decrypt
 
 
+class KMSSecretKeySet:
+    """Key material of the KMS multi-key scheme (mk_bootstrap_new): per party SecretKey_new (binary LWE key), RLweKey (binary),
+    PublicKey b_l = s (*) a_l + e over the shared a (SharedKey_new: the uni gadget), and BootstrapKeyPart_new (new_mk_internals.jl:1-42):
+    a fresh binary `rand_key`, gsw_key[j] = tgsw_encrypt(lwe_key[j]) under rand_key (tgsw.jl:88-101 -> rlwe_encrypt_zero rlwe.jl:79-105)
+    and the uni-encryption (d1, f0, f1) of the POLYNOMIAL rand_key (mk_tgsw_encrypt, mk_internals.jl:390-446; c0, c1, d0 are never read
+    by UniProduct_new), plus a KeyswitchKey from the RLWE key to the LWE key (mk_api.jl:418-436).
+    Tables: gsw int64[P][n][2 l_gsw][2][N] (row = block * l + level, column 0 mask / 1 body), uni int64[P][3][l_uni][N], pk int64[P][l_uni][N],
+    crs int64[l_uni][N], ksk int32[P][N][t][base-1][n+1]."""
+
+    def __init__(self, params, seed=0x5EED0001, sigma_lwe=3.05e-5, sigma_gsw=4.63e-18, sigma_uni=4.63e-18, sigma_ks=3.05e-5):
+        p = self.params = params
+        rng = np.random.default_rng(seed)
+        P, n, N = p.parties, p.n, p.N
+        lg, lu = p.l_gsw, p.l_uni
+        self.sigma_lwe = sigma_lwe
+        self.lwe_keys = rng.integers(0, 2, (P, n)).astype(np.int32)
+        self.rlwe_keys = rng.integers(0, 2, (P, N)).astype(np.int64)
+        rand_keys = rng.integers(0, 2, (P, N)).astype(np.int64)
+        self.crs = rng.integers(-2**63, 2**63, size=(lu, N), dtype=np.int64)
+        gauss = lambda shape, sig: dtot64(rng.standard_normal(shape) * sig).view(np.uint64)
+        u64 = lambda a: np.ascontiguousarray(a).view(np.uint64)
+        g_gsw = [np.uint64(64 - (q + 1) * p.bg_gsw) for q in range(lg)]
+        g_uni = [np.uint64(64 - (q + 1) * p.bg_uni) for q in range(lu)]
+        self.pk = np.stack([u64(polymul_small64(self.crs, self.rlwe_keys[q])) + gauss((lu, N), sigma_uni) for q in range(P)]).view(np.int64)
+        gsw = np.empty((P, n, 2 * lg, 2, N), np.uint64)
+        uni = np.empty((P, 3, lu, N), np.uint64)
+        for q in range(P):
+            mask = rng.integers(-2**63, 2**63, size=(n * 2 * lg, N), dtype=np.int64)
+            body = u64(polymul_small64(mask, rand_keys[q])) + gauss(mask.shape, sigma_gsw)
+            gsw[q, :, :, 0, :] = u64(mask).reshape(n, 2 * lg, N)
+            gsw[q, :, :, 1, :] = body.reshape(n, 2 * lg, N)
+            m = self.lwe_keys[q].astype(np.uint64)
+            for blk in range(2):               # + m * gadget on the constant coefficient of polynomial `blk` of row (blk, level)
+                for lv in range(lg):
+                    gsw[q, :, blk * lg + lv, blk, 0] += m << g_gsw[lv]
+            r = rng.integers(0, 2, N).astype(np.int64)
+            f1 = rng.integers(-2**63, 2**63, size=(lu, N), dtype=np.int64)
+            uni[q, 0] = u64(polymul_small64(self.crs, r)) + gauss((lu, N), sigma_uni)
+            uni[q, 1] = u64(polymul_small64(f1, self.rlwe_keys[q])) + gauss((lu, N), sigma_uni)
+            for lv in range(lu):
+                uni[q, 0, lv] += rand_keys[q].astype(np.uint64) << g_uni[lv]     # d1_l = e + r (*) a_l + rand_key * g_l
+                uni[q, 1, lv] += r.astype(np.uint64) << g_uni[lv]                # f0_l = e + s (*) f1_l + r * g_l
+            uni[q, 2] = u64(f1)
+        self.gsw, self.uni = gsw.view(np.int64), uni.view(np.int64)
+        self.ksk = np.stack([gen_keyswitch_key(rng, self.rlwe_keys[q], self.lwe_keys[q], p.ks_t, p.ks_basebit, sigma_ks) for q in range(P)])
+
+    encrypt = MKSecretKeySet.encrypt
+    phase = MKSecretKeySet.phase
+    decrypt = MKSecretKeySet.decrypt
+
+
 def negacyclic_matrix_u64(b):
     """Three float64 limb matrices of the torus polynomial b: small (*) b = sum_limb (small @ M_limb) << shift."""
     b = np.asarray(b).view(np.uint64)
