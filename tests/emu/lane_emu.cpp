@@ -225,6 +225,25 @@ void emu_inv_raw(const double *in, double *zout) {
 }
 
 extern "C" {
+// the fused rotate + decompose of the second-generation ring kernel must give the digits of load_rotated16 + digits_to_z; returns mismatches
+int emu_rotated_digits_crosscheck(const int32_t *acc /*[1024]*/, int a2n, int l, int Bgbit) {
+    int bad = 0;
+    const uint32_t offset = decomp_offset32(l, Bgbit);
+    for (int lane = 0; lane < 64; lane++) {
+        uint32_t t[16];
+        load_rotated16(lane, acc, a2n, offset, t);
+        for (int p = 1; p <= l; p++) {
+            cplx z0[8], z1[8];
+            digits_to_z(t, p, Bgbit, z0);
+            rotated_digits_z(lane, acc, a2n, p, l, Bgbit, z1);
+            for (int m = 0; m < 8; m++) bad += (z0[m].re != z1[m].re) + (z0[m].im != z1[m].im);
+        }
+    }
+    return bad;
+}
+}
+
+extern "C" {
 // swizzled-variant transforms must give the same spectra (same register order) as the padded variant, and the same
 // exact products: forward with one variant, inverse with the other.
 double emu_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out) {

@@ -123,6 +123,16 @@ def test_roots_variant_exact_with_margin(E, O, case, fn):
     assert margin < 1e-4 and dmax.value < 1e-8, (margin, dmax.value)
 
 
+def test_fused_rotated_digits_match_reference_form(E):
+    # rotated_digits_z (one signed bit-field extract per digit, sign by xor/subtract) == load_rotated16 + digits_to_z on random and
+    # extreme accumulators, every rotation class (0, < N, = N, > N, 2N - 1) and the three gadget shapes in use
+    rng = np.random.default_rng(33)
+    for acc in (rng.integers(-2**31, 2**31, 1024).astype(np.int32), np.full(1024, -2**31, np.int32), np.full(1024, 2**31 - 1, np.int32)):
+        for a2n in (0, 1, 63, 64, 1023, 1024, 1025, 2047, int(rng.integers(0, 2048))):
+            for l, bg in ((3, 7), (2, 10), (4, 8), (1, 4)):
+                assert E.emu_rotated_digits_crosscheck(acc.ctypes.data_as(C.POINTER(C.c_int32)), a2n, l, bg) == 0, (a2n, l, bg)
+
+
 def test_mk_cmux_and_extract_bit_exact(E, O):
     # Torus64 3-gen CMux through the lane code (four 16-bit limbs, hi-word digits) vs the MK oracle's schoolbook path
     for name, n, parties in (("MK2", 6, 2), ("MK4", 3, 2)):

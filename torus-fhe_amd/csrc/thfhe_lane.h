@@ -387,6 +387,32 @@ THFHE_FN void digits_to_z(const uint32_t (&t)[16], int p, int Bgbit, cplx (&z)[8
 #pragma unroll
     for (int m = 0; m < 8; m++) z[m] = cplx{digit32(t[m], shift, mask, half), digit32(t[m + 8], shift, mask, half)};
 }
+// Fused form of load_rotated16 + digits_to_z for kernels that re-read the accumulator per digit level (second-generation ring kernel):
+// z[m] = (digit_p of (X^a acc - acc)[lane + 64 m], digit_p of ...[lane + 64 m + 512]), level p = 1..l.  Fewer integer instructions:
+//   * e = (lane - a) mod 2N is formed once; e + 64 m needs no second reduction (bit 10 of the sum is the sign, bits 0..9 the index);
+//   * the sign is applied as (r ^ M) - M with M = -sign (a one-bit signed field extract);
+//   * the balanced digit is ONE signed bit-field extract of v + offset + half_p, half_p = half a digit at level p: adding it turns the
+//     unsigned field F of the reference's ((v + offset) >> shift) & mask - Bg/2 (J/tgsw.jl:125-137) into (F + Bg/2) mod Bg, whose
+//     two's-complement reading is F - Bg/2 (carries of the addition only travel upwards, out of the field).
+THFHE_FN void rotated_digits_z(int lane, const int32_t *p, int a2n, int level, int l, int Bgbit, cplx (&z)[8]) {
+    const int shift = 32 - level * Bgbit;
+    const uint32_t off = decomp_offset32(l, Bgbit) + ((1u << (Bgbit - 1)) << shift);
+    const uint32_t e0 = (uint32_t)(lane - a2n) & 2047u;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        double d[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = lane + 64 * m + 512 * q;          // coefficient index
+            const uint32_t e = e0 + (uint32_t)(64 * m + 512 * q);
+            const uint32_t r = (uint32_t)p[e & 1023u];
+            const uint32_t M = (uint32_t)((int32_t)(e << 21) >> 31);   // -1 where bit 10 of e is set (X^a wraps with a sign flip)
+            const uint32_t v = ((r ^ M) - M) - (uint32_t)p[c] + off;
+            d[q] = (double)((int32_t)(v << (32 - shift - Bgbit)) >> (32 - Bgbit));
+        }
+        z[m] = cplx{d[0], d[1]};
+    }
+}
 // s += z * b as four fused multiply-adds (two dependent pairs)
 THFHE_FN void cfma(cplx &s, cplx z, cplx b) {
     s.re = __builtin_fma(z.re, b.re, s.re);

@@ -161,7 +161,6 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
     cplx *xb = sX[wave];
     const int32_t *bara = a.bara + (has_job ? job : 0) * a.n_pad;
     const int Bgbit = a.Bgbit;
-    const uint32_t offset = decomp_offset32(L, Bgbit);
     if (has_job) acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
 
     const long total_chunks = (long)a.n * ROWS * 4;
@@ -201,11 +200,9 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
             if (active) {
                 // the rotated differences are re-read from the accumulator for every level: 32 LDS dwords per row cost less than keeping
                 // 16 registers alive across the transform and the multiply (the compiler spilled them to scratch: a far longer round trip)
-                uint32_t t[16];
                 int a2n_r = a2n;
                 asm volatile("" : "+s"(a2n_r));  // opaque per row: the 16 rotated LDS addresses are recomputed (3 integer ops each), not kept alive
-                load_rotated16(lane, acc + (r / L) * 1024, a2n_r, offset, t);
-                digits_to_z(t, (r % L) + 1, Bgbit, z);
+                rotated_digits_z(lane, acc + (r / L) * 1024, a2n_r, (r % L) + 1, L, Bgbit, z);
                 if (V & 1) wave_fft_fwd_q(lane, z, xb, roots, w64); else wave_fft_fwd_r(lane, z, xb, roots, w64);
             }
             STAMP(0);
@@ -244,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
             wave_sync();
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                if (V & 1) {
+                if ((V & 1) && !(V & 2)) {
                     wave_fft_inv_q(lane, S[c][0], xb, roots, w64);
                     wave_fft_inv_q(lane, S[c][1], xb, roots, w64);
                 } else {
@@ -297,7 +294,6 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
     const long job = blockIdx.x;
     const int32_t *bara = a.bara + job * a.n_pad;
     const int Bgbit = a.Bgbit;
-    const uint32_t offset = decomp_offset32(L, Bgbit);
     if (wave == 0) acc_init16(lane, sAcc, sAcc + 1024, a.barb[job], a.mu);
     const int c = (wave >> 1) & 1, h = wave & 1, half = wave >> 2, r0 = half * L;  // role in M: rows r0 .. r0+L-1 of (column c, limb h)
     unsigned int *ap = reinterpret_cast<unsigned int *>(sAcc) + c * 1024;
@@ -319,10 +315,8 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
         const int inl = inext < a.n ? inext : i;   // the last step re-requests its own chunks: unconditional loads keep B one set of registers
         // ---- F ----
         if (wave < ROWS) {
-            uint32_t t[16];
             cplx z[8];
-            load_rotated16(lane, sAcc + (wave / L) * 1024, a2n, offset, t);
-            digits_to_z(t, (wave % L) + 1, Bgbit, z);
+            rotated_digits_z(lane, sAcc + (wave / L) * 1024, a2n, (wave % L) + 1, L, Bgbit, z);
             wave_fft_fwd_q(lane, z, xb, roots, w64);
 #pragma unroll
             for (int m = 0; m < 8; m++) sSpec[wave][m * 64 + lane] = z[m];
@@ -688,6 +682,7 @@ void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
 #ifdef THFHE_VARIANTS  // developer A/B builds only: 8 = first transpose through the LDS (variant "r")
     static const int variant = std::getenv("THFHE_RING_VARIANT") ? std::atoi(std::getenv("THFHE_RING_VARIANT")) : 0;
     if (variant == 8) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 0>), grid, block, 0, s, a); return; }
+    if (variant == 3) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 3>), grid, block, 0, s, a); return; }   // forward in registers, inverse through the LDS
 #endif
     hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 1>), grid, block, 0, s, a);
 }
