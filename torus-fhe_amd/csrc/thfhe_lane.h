@@ -394,21 +394,38 @@ THFHE_FN void digits_to_z(const uint32_t (&t)[16], int p, int Bgbit, cplx (&z)[8
 //   * the balanced digit is ONE signed bit-field extract of v + offset + half_p, half_p = half a digit at level p: adding it turns the
 //     unsigned field F of the reference's ((v + offset) >> shift) & mask - Bg/2 (J/tgsw.jl:125-137) into (F + Bg/2) mod Bg, whose
 //     two's-complement reading is F - Bg/2 (carries of the addition only travel upwards, out of the field).
+//   * device form: byte offsets (one add + one mask per rotated address, the polynomial being 4 KiB-aligned in LDS), sign applied as
+//     (r + M) ^ M, the level-dependent constant folded with the unrotated word, v_bfe_i32 for sign and digit: 8 integer instructions +
+//     1 conversion per coefficient (the portable form compiles to 10-11).
+THFHE_FN int32_t sbfe32(uint32_t v, int shift, int width) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sbfe((int32_t)v, (uint32_t)shift, (uint32_t)width);
+#else
+    return (int32_t)(v << (32 - shift - width)) >> (32 - width);
+#endif
+}
 THFHE_FN void rotated_digits_z(int lane, const int32_t *p, int a2n, int level, int l, int Bgbit, cplx (&z)[8]) {
     const int shift = 32 - level * Bgbit;
     const uint32_t off = decomp_offset32(l, Bgbit) + ((1u << (Bgbit - 1)) << shift);
-    const uint32_t e0 = (uint32_t)(lane - a2n) & 2047u;
+    const uint32_t e4 = ((uint32_t)(lane - a2n) & 2047u) << 2;   // byte offset of coefficient (lane - a) mod 2N, bit 12 = sign
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t base = (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)p;   // LDS, 4 KiB-aligned (the kernels' sAcc)
+#endif
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         double d[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int c = lane + 64 * m + 512 * q;          // coefficient index
-            const uint32_t e = e0 + (uint32_t)(64 * m + 512 * q);
-            const uint32_t r = (uint32_t)p[e & 1023u];
-            const uint32_t M = (uint32_t)((int32_t)(e << 21) >> 31);   // -1 where bit 10 of e is set (X^a wraps with a sign flip)
-            const uint32_t v = ((r ^ M) - M) - (uint32_t)p[c] + off;
-            d[q] = (double)((int32_t)(v << (32 - shift - Bgbit)) >> (32 - Bgbit));
+            const uint32_t f = e4 + (uint32_t)(256 * m + 2048 * q);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t r = (uint32_t) * (__attribute__((address_space(3))) const int32_t *)(size_t)(base | (f & 0xFFCu));
+#else
+            const uint32_t r = (uint32_t)p[(f & 0xFFCu) >> 2];
+#endif
+            const uint32_t M = (uint32_t)sbfe32(f, 12, 1);   // -1 where X^a wraps with a sign flip
+            const uint32_t v = ((r + M) ^ M) + (off - (uint32_t)p[c]);
+            d[q] = (double)sbfe32(v, shift, Bgbit);
         }
         z[m] = cplx{d[0], d[1]};
     }

@@ -147,7 +147,7 @@ struct BRArgs {
 // ------------------------------------------------------------------------------------------------------
 template <int L, int V = 1>
 __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) {
-    __shared__ int32_t sAcc[8][2048];
+    __shared__ __attribute__((aligned(4096))) int32_t sAcc[8][2048];   // rotated_digits_z ORs byte offsets into the polynomial base
     __shared__ cplx sX[8][kXbufSlots];
     __shared__ cplx sRing[3][512];
     constexpr int ROWS = 2 * L;
@@ -284,7 +284,7 @@ __device__ __forceinline__ void pin() { asm volatile("" ::: "memory"); }  // mem
 template <int L, int PACE = 1>
 __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) {
     constexpr int ROWS = 2 * L;
-    __shared__ int32_t sAcc[2048];
+    __shared__ __attribute__((aligned(4096))) int32_t sAcc[2048];
     __shared__ cplx sSpec[ROWS][512];
     __shared__ cplx sX[8][kXbufSlots];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
