@@ -237,6 +237,13 @@ int emu_rotated_digits_crosscheck(const int32_t *acc /*[1024]*/, int a2n, int l,
             digits_to_z(t, p, Bgbit, z0);
             rotated_digits_z(lane, acc, a2n, p, l, Bgbit, z1);
             for (int m = 0; m < 8; m++) bad += (z0[m].re != z1[m].re) + (z0[m].im != z1[m].im);
+            uint32_t f7[7], f12[16];   // two-step form (fields once per polynomial, one extract per level), some / all fields kept
+            rotated_fields_keep<7>(lane, acc, a2n, l, Bgbit, f7);
+            mixed_digits_z<7>(lane, acc, a2n, p, l, Bgbit, f7, z1);
+            for (int m = 0; m < 8; m++) bad += (z0[m].re != z1[m].re) + (z0[m].im != z1[m].im);
+            rotated_fields_keep<16>(lane, acc, a2n, l, Bgbit, f12);
+            mixed_digits_z<16>(lane, acc, a2n, p, l, Bgbit, f12, z1);
+            for (int m = 0; m < 8; m++) bad += (z0[m].re != z1[m].re) + (z0[m].im != z1[m].im);
         }
     }
     return bad;

@@ -161,7 +161,8 @@ __device__ __forceinline__ void wave_transpose_hi3(cplx (&z)[8]) {
 #pragma unroll
     for (int r = 0; r < 8; r++) __builtin_memcpy(&z[r], w[r], 16);
 }
-__device__ __forceinline__ void wave_fft_fwd_q(int lane, cplx (&z)[8], cplx *xb, const LaneRoots &r, const W64 &w) {
+template <class Roots>
+__device__ __forceinline__ void wave_fft_fwd_q(int lane, cplx (&z)[8], cplx *xb, const Roots &r, const W64 &w) {
     fwdq_seg1(z, r);
     wave_transpose_hi3(z);
     wave_sync();
@@ -169,7 +170,8 @@ __device__ __forceinline__ void wave_fft_fwd_q(int lane, cplx (&z)[8], cplx *xb,
     wave_sync();
     fwd_seg3(lane, z, xb);
 }
-__device__ __forceinline__ void wave_fft_inv_q(int lane, cplx (&z)[8], cplx *xb, const LaneRoots &r, const W64 &w) {
+template <class Roots>
+__device__ __forceinline__ void wave_fft_inv_q(int lane, cplx (&z)[8], cplx *xb, const Roots &r, const W64 &w) {
     wave_sync();
     invr_seg1(lane, z, xb, w);
     wave_sync();

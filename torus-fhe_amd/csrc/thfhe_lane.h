@@ -328,6 +328,51 @@ THFHE_FN void invq_seg3(cplx (&z)[8], const LaneRoots &r) {
     for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
 }
 
+// Register-lean form of the "q" pass-1 twiddles for kernels at the VGPR limit (LDS-ring kernel): the compiler hoists the eight products
+// b s^k0 of fwdq_seg1 out of the CMux loop (32 VGPRs) and then spills some of them; here only the even ones e_j = b s^(2j) live across
+// the loop (16 VGPRs + s), the odd ones e_j s are formed in place (four more complex products per transform).  `s` is passed through an
+// empty asm so that these products are not hoisted as well.
+struct LaneTw {
+    cplx e[4], s;
+};
+THFHE_FN LaneTw make_lane_tw(const LaneRoots &r) {
+    LaneTw t;
+    const cplx s2 = cmul(r.s, r.s);
+    t.e[0] = r.b;
+#pragma unroll
+    for (int j = 1; j < 4; j++) t.e[j] = cmul(t.e[j - 1], s2);
+    t.s = r.s;
+    return t;
+}
+THFHE_FN cplx opaque_cplx(cplx v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v.re), "+v"(v.im));
+#endif
+    return v;
+}
+THFHE_FN void fwdq_seg1(cplx (&z)[8], const LaneTw &t) {
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+    dft8<+1>(z);
+    const cplx s = opaque_cplx(t.s);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        z[2 * j] = cmul(z[2 * j], t.e[j]);
+        z[2 * j + 1] = cmul(z[2 * j + 1], cmul(t.e[j], s));
+    }
+}
+THFHE_FN void invq_seg3(cplx (&z)[8], const LaneTw &t) {
+    const cplx s = opaque_cplx(t.s);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        z[2 * j] = cmul_conj(z[2 * j], t.e[j]);
+        z[2 * j + 1] = cmul_conj(z[2 * j + 1], cmul(t.e[j], s));
+    }
+    dft8<-1>(z);
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
+}
+
 // ---- integer helpers ---------------------------------------------------------------------------------
 // coefficient q of X^a * p - p for p in LDS, a in [0, 2N)          (mul_by_monomial, J/rlwe.jl:130-131)
 THFHE_FN uint32_t rot_minus_self32(const int32_t *p, int q, int a2n, int N) {
@@ -429,6 +474,42 @@ THFHE_FN void rotated_digits_z(int lane, const int32_t *p, int a2n, int level, i
         }
         z[m] = cplx{d[0], d[1]};
     }
+}
+// Two-step form: index, sign and subtraction are done once per coefficient and polynomial, a level then costs one signed bit-field
+// extract and one conversion:   t = ((X^a acc - acc) + offset) ^ offset,  offset = sum_p (Bg/2) << (32 - p Bgbit).
+// XOR with Bg/2 inside a field is "+ Bg/2 mod Bg" without carries into the neighbouring fields, so the two's-complement reading of
+// field p of t is F_p - Bg/2, the reference's balanced digit (J/tgsw.jl:125-137).  The fields of the first NF coefficients this lane
+// owns are kept across the levels of a polynomial, the other 16 - NF are re-read per level as in rotated_digits_z (NF = 16 in the
+// LDS-ring kernel: the compiler parks some of the fields in scratch, which measured faster than re-reading them -- 29.9 ms per 4096
+// gates against 30.1 for NF = 8 and 30.5 for the largest spill-free NF = 5).  Coefficient j = lane + 64 j (j < 16).
+THFHE_FN uint32_t rotated_word(int lane, const int32_t *p, uint32_t e4, int j, uint32_t off) {
+    const uint32_t f = e4 + (uint32_t)(256 * j);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t base = (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)p;   // LDS, 4 KiB-aligned
+    const uint32_t r = (uint32_t) * (__attribute__((address_space(3))) const int32_t *)(size_t)(base | (f & 0xFFCu));
+#else
+    const uint32_t r = (uint32_t)p[(f & 0xFFCu) >> 2];
+#endif
+    const uint32_t M = (uint32_t)sbfe32(f, 12, 1);
+    return ((r + M) ^ M) + (off - (uint32_t)p[lane + 64 * j]);
+}
+template <int NF>
+THFHE_FN void rotated_fields_keep(int lane, const int32_t *p, int a2n, int l, int Bgbit, uint32_t (&t)[NF]) {
+    const uint32_t off = decomp_offset32(l, Bgbit);
+    const uint32_t e4 = ((uint32_t)(lane - a2n) & 2047u) << 2;
+#pragma unroll
+    for (int j = 0; j < NF; j++) t[j] = rotated_word(lane, p, e4, j, off) ^ off;
+}
+template <int NF>
+THFHE_FN void mixed_digits_z(int lane, const int32_t *p, int a2n, int level, int l, int Bgbit, const uint32_t (&t)[NF], cplx (&z)[8]) {
+    const int shift = 32 - level * Bgbit;
+    const uint32_t off = decomp_offset32(l, Bgbit) + ((1u << (Bgbit - 1)) << shift);
+    const uint32_t e4 = ((uint32_t)(lane - a2n) & 2047u) << 2;
+    double d[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) d[j] = (double)sbfe32(j < NF ? t[j < NF ? j : 0] : rotated_word(lane, p, e4, j, off), shift, Bgbit);
+#pragma unroll
+    for (int m = 0; m < 8; m++) z[m] = cplx{d[m], d[m + 8]};
 }
 // s += z * b as four fused multiply-adds (two dependent pairs)
 THFHE_FN void cfma(cplx &s, cplx z, cplx b) {

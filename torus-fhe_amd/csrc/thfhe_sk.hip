@@ -141,10 +141,18 @@ struct BRArgs {
 //   * the multiply-accumulate is software-pipelined over half chunks: the four ring reads of one half are in flight under the
 //     16 FMAs of the half before (the first generation read one slice, used it, read the next: 8 serial round trips per chunk),
 //     and S += z * b is four FMAs (the mul + fma + add form cost 384 more FP64 instructions per CMux);
-//   * the rotated differences X^a acc - acc are re-read from the accumulator for every digit level instead of living in 16
-//     registers across transform and multiply (the compiler had spilled them to scratch).
 // LDS pipe instructions per launch 1.74e9 -> 1.38e9, LDS pipe busy 69 % -> 46 %, VALU busy 55 % -> 75 %, 34.8 -> 33.3 ms per 4096 gates.
+// Third pass (33.3 -> 29.9 ms):
+//   * rotate + decompose in one step on byte offsets (thfhe_lane.h: rotated_word / mixed_digits_z), the index / sign / subtraction
+//     work once per accumulator polynomial (fields kept across its l levels), a level = one v_bfe_i32 + one conversion per coefficient;
+//   * register-lean pass-1 twiddles (LaneTw): the compiler hoists loop-invariant twiddle products out of the CMux loop and then spills
+//     some of them; every reload was followed by s_waitcnt vmcnt(0), which also waits for the ring DMAs issued just before the
+//     transform.  Keeping only the even products and forming the odd ones in place (16 more FP64 instructions per transform) removes
+//     those reloads from the transforms.
 // ------------------------------------------------------------------------------------------------------
+#ifndef THFHE_RING_NF
+#define THFHE_RING_NF 16
+#endif
 template <int L, int V = 1>
 __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) {
     __shared__ __attribute__((aligned(4096))) int32_t sAcc[8][2048];   // rotated_digits_z ORs byte offsets into the polynomial base
@@ -155,6 +163,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
     const int lane = threadIdx.x & 63;
     const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
     const LaneRoots roots{a.tw[576 + 2 * lane], a.tw[576 + 2 * lane + 1]};
+    const LaneTw tw = make_lane_tw(roots);
     const long job = (long)blockIdx.x * 8 + wave;
     const bool has_job = job < a.jobs;
     int32_t *acc = sAcc[wave];
@@ -194,16 +203,19 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
             for (int h = 0; h < 2; h++)
 #pragma unroll
                 for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
+        constexpr int NF = THFHE_RING_NF;   // rotated fields kept across the levels of a polynomial (register budget)
+        uint32_t fld[NF];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             cplx z[8];
             if (active) {
-                // the rotated differences are re-read from the accumulator for every level: 32 LDS dwords per row cost less than keeping
-                // 16 registers alive across the transform and the multiply (the compiler spilled them to scratch: a far longer round trip)
+                // index / sign / subtraction once per accumulator polynomial, then one signed bit-field extract + one conversion per level
                 int a2n_r = a2n;
-                asm volatile("" : "+s"(a2n_r));  // opaque per row: the 16 rotated LDS addresses are recomputed (3 integer ops each), not kept alive
-                rotated_digits_z(lane, acc + (r / L) * 1024, a2n_r, (r % L) + 1, L, Bgbit, z);
-                if (V & 1) wave_fft_fwd_q(lane, z, xb, roots, w64); else wave_fft_fwd_r(lane, z, xb, roots, w64);
+                asm volatile("" : "+s"(a2n_r));  // opaque per row: the rotated LDS addresses are recomputed, not kept alive
+                if (r % L == 0) rotated_fields_keep<NF>(lane, acc + (r / L) * 1024, a2n_r, L, Bgbit, fld);
+                asm volatile("" : "+s"(a2n_r));
+                mixed_digits_z<NF>(lane, acc + (r / L) * 1024, a2n_r, (r % L) + 1, L, Bgbit, fld, z);
+                if (V & 1) wave_fft_fwd_q(lane, z, xb, tw, w64); else wave_fft_fwd_r(lane, z, xb, roots, w64);
             }
             STAMP(0);
             cplx bA[4], bB[4];
@@ -242,8 +254,8 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 if ((V & 1) && !(V & 2)) {
-                    wave_fft_inv_q(lane, S[c][0], xb, roots, w64);
-                    wave_fft_inv_q(lane, S[c][1], xb, roots, w64);
+                    wave_fft_inv_q(lane, S[c][0], xb, tw, w64);
+                    wave_fft_inv_q(lane, S[c][1], xb, tw, w64);
                 } else {
                     wave_fft_inv_r(lane, S[c][0], xb, roots, w64);
                     wave_fft_inv_r(lane, S[c][1], xb, roots, w64);
