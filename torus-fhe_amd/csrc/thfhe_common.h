@@ -60,6 +60,13 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
+// The lane index behind an empty asm: everything derived from it (the XOR-swizzled LDS slot maps: ~25 addresses of 1-3 integer
+// instructions each) is recomputed where it is used.  Without it the compiler hoists those addresses out of the CMux loop as
+// loop invariants and, being at the VGPR limit, spills them to scratch.
+__device__ __forceinline__ int opaque_lane(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
 // forward / inverse folded negacyclic transform of the 8 points each lane holds (see thfhe_lane.h)
 __device__ __forceinline__ void wave_fft_fwd(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const cplx *T2) {
     wave_sync();

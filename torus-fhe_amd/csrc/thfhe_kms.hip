@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void kms_tlev_rotate_kernel(KmsBRArgs a) {
     int i = 0;
     while (i < a.n && bara[i] == 0) i++;
     while (i < a.n) {
-        const int a2n = bara[i] & 4095;
+        const int a2n = __builtin_amdgcn_readfirstlane(bara[i]) & 4095;   // uniform over the workgroup
         int inext = i + 1;
         while (inext < a.n && bara[inext] == 0) inext++;
         cplx S0[8], S1[8];
@@ -112,12 +112,14 @@ __global__ __launch_bounds__(512, 2) void kms_tlev_rotate_kernel(KmsBRArgs a) {
                 const int32_t half_bg = 1 << (bg - 1), half_lo = 1 << (lo_bits - 1), mask_lo = (1 << lo_bits) - 1;
                 constexpr double R = 0.70710678118654752440;
                 cplx y0[8], y1[8];
+                int a2n_b = a2n;
+                asm volatile("" : "+s"(a2n_b));   // opaque per batch: the 32 rotated indices and sign predicates are recomputed, not kept (spilled) across batches
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
                     double d[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const uint64_t v = rot_minus_self64_n<2048>(ap, lane + 64 * m + 512 * q, a2n) + offset;
+                        const uint64_t v = rot_minus_self64_n<2048>(ap, lane + 64 * m + 512 * q, a2n_b) + offset;
                         int32_t dg = (int32_t)((v >> shift) & mask) - half_bg;                     // decompose, J/tgsw.jl:112-138 (64-bit words)
                         if (parts == 2) {
                             const int32_t lo = ((dg + half_lo) & mask_lo) - half_lo;               // balanced low part
@@ -131,8 +133,12 @@ __global__ __launch_bounds__(512, 2) void kms_tlev_rotate_kernel(KmsBRArgs a) {
                     if (m & 1) kms_pin();   // at most 8 of the 32 rotated 64-bit reads in flight: the partial spectra keep 64 registers busy here
                 }
                 cplx *xb = sSpec + wave * 1024;
-                wave_fft_fwd_t<1>(lane, y0, xb, sT1[0], w64);
-                wave_fft_fwd_t<5>(lane, y1, xb, sT1[1], w64);
+                // the swizzled LDS slot maps are a few integer operations per address: recomputed here (opaque lane) instead of hoisted out
+                // of the CMux loop by the compiler, which then spilled the 25 address registers to scratch
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                wave_fft_fwd_t<1>(ln, y0, xb, sT1[0], w64);
+                wave_fft_fwd_t<5>(ln, y1, xb, sT1[1], w64);
                 wave_sync();
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
@@ -167,8 +173,10 @@ __global__ __launch_bounds__(512, 2) void kms_tlev_rotate_kernel(KmsBRArgs a) {
         }
         {
             cplx *xb = sSpec + wave * 512;
-            wave_fft_inv_t<1>(lane, S0, xb, sT1[0], w64);
-            wave_fft_inv_t<5>(lane, S1, xb, sT1[1], w64);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            wave_fft_inv_t<1>(ln, S0, xb, sT1[0], w64);
+            wave_fft_inv_t<5>(ln, S1, xb, sT1[1], w64);
             cplx lo[8], hi[8];
             merge2048(S0, S1, lo, hi);
 #pragma unroll

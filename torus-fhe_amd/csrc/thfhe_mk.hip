@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a
             cplx z[8];
             load_rotated16_hi(lane, sAcc + (wave / L) * 1024, a2n, offset, t);
             digits_to_z(t, (wave % L) + 1, Bgbit, z);
-            wave_fft_fwd_s(lane, z, sX[wave], sT1, w64);
+            wave_fft_fwd_s(opaque_lane(lane), z, sX[wave], sT1, w64);
 #pragma unroll
             for (int m = 0; m < 8; m++) sSpec[wave][m * 64 + lane] = z[m];
         }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a
             mac8r(S, z, B[r % PRE]);
             if (r + PRE < ROWS) load8(lane, B[r % PRE], a.bk + mk_chunk_index(i, r + PRE, h, o, ROWS) * 512);
         }
-        wave_fft_inv_s(lane, S, sX[wave], sT1, w64);
+        wave_fft_inv_s(opaque_lane(lane), S, sX[wave], sT1, w64);
 #pragma unroll
         for (int m = 0; m < 8; m++) {
             const int q = lane + 64 * m;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
                     load_rotated16_hi(lane, sAcc[g] + (r / L) * 1024, ai & 2047, offset, t);
                     digits_to_z(t, (r % L) + 1, Bgbit, z);
                     cplx *slot = sSpec + f * 512;  // transposes run inside the task's own, not yet published, spectrum slot
-                    wave_fft_fwd_s(lane, z, slot, sT1, w64);
+                    wave_fft_fwd_s(opaque_lane(lane), z, slot, sT1, w64);
                     wave_sync();
 #pragma unroll
                     for (int m = 0; m < 8; m++) slot[m * 64 + lane] = z[m];
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
         cplx *xb = sSpec + wave * 512;
         if (ai0 != 0) {
             unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[0]) + o * 1024;
-            wave_fft_inv_s(lane, S0, xb, sT1, w64);
+            wave_fft_inv_s(opaque_lane(lane), S0, xb, sT1, w64);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int q = lane + 64 * m;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
         }
         if (ai1 != 0) {
             unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[1]) + o * 1024;
-            wave_fft_inv_s(lane, S1, xb, sT1, w64);
+            wave_fft_inv_s(opaque_lane(lane), S1, xb, sT1, w64);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int q = lane + 64 * m;
@@ -371,8 +371,10 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
                 }
             }
             cplx *xb = sSpec + wave * 1024;
-            wave_fft_fwd_t<1>(lane, y0, xb, sT1[0], w64);
-            wave_fft_fwd_t<5>(lane, y1, xb, sT1[1], w64);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));   // the swizzled LDS slot maps are recomputed here, not hoisted out of the CMux loop and spilled
+            wave_fft_fwd_t<1>(ln, y0, xb, sT1[0], w64);
+            wave_fft_fwd_t<5>(ln, y1, xb, sT1[1], w64);
             wave_sync();
 #pragma unroll
             for (int m = 0; m < 8; m++) {
@@ -407,8 +409,10 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
         STAMP(4);
         {
             cplx *xb = sSpec + wave * 512;
-            wave_fft_inv_t<1>(lane, S0, xb, sT1[0], w64);
-            wave_fft_inv_t<5>(lane, S1, xb, sT1[1], w64);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            wave_fft_inv_t<1>(ln, S0, xb, sT1[0], w64);
+            wave_fft_inv_t<5>(ln, S1, xb, sT1[1], w64);
             cplx lo[8], hi[8];
             merge2048(S0, S1, lo, hi);
 #pragma unroll
