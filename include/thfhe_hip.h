@@ -220,6 +220,8 @@ int thfhe_pm_mac(thfhe_pm_ctx *ctx, const int32_t *small, size_t n_small, const 
  *   ksk  int32[P][N][t][base-1][n+1]
  * thfhe_kms_tlev_rotate   <- mk_ith_blind_rotate: for `count` gates, party `party`: bara int32[count][n] (the party's mod-switched mask
  *                            words) -> lev int64[count][l_lev][2][N], the rotated TLev accumulator (mask, body per level)
+ * thfhe_kms_rlwe_rotate   <- mk_single_blind_rotate (new_mk_internals.jl:226-238, the fast_boot route :255-269): acc int64[count][2][N]
+ *                            (mask, body), rotated in place by the party's n TGSW-encrypted key bits
  * thfhe_kms_keyswitch     <- mk_keyswitch (mk_internals.jl:714-728): u int32[count][P N + 1] -> out int32[count][P n + 1]
  * The products between the two (tlev_extern_mul, UniProduct_new) go through thfhe_pm_mac under the host layer (thfhe/kms.py). */
 typedef struct {
@@ -233,6 +235,7 @@ typedef struct thfhe_kms_ctx thfhe_kms_ctx;
 int thfhe_kms_ctx_create(const thfhe_kms_params *p, const int64_t *gsw, const int32_t *ksk, int device, thfhe_kms_ctx **out);
 void thfhe_kms_ctx_destroy(thfhe_kms_ctx *ctx);
 int thfhe_kms_tlev_rotate(thfhe_kms_ctx *ctx, int party, const int32_t *bara, int64_t *lev, size_t count);
+int thfhe_kms_rlwe_rotate(thfhe_kms_ctx *ctx, int party, const int32_t *bara, int64_t *acc, size_t count);
 int thfhe_kms_keyswitch(thfhe_kms_ctx *ctx, const int32_t *u, int32_t *out, size_t count);
 
 #ifdef __cplusplus

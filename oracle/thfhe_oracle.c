@@ -1201,29 +1201,34 @@ static void kms_mulacc(const int64_t *small, const int64_t *torus, int N, int64_
 
 /* mk_ith_blind_rotate: TLev accumulator of party `party`      J/new_mk_internals.jl:210-225, mk_mux_rotate_new :177-182,
  * tlev_trivial_int J/tlev.jl:37-45, tgsw_intern_mul J/tlev.jl:85-92 (tgsw_extern_mul per TLev sample, J/tgsw.jl:146-156) */
-void oracle_kms_tlev_rotate(const oracle_kms_ctx *c, int32_t party, const int32_t *bara, int64_t *lev, int use_schoolbook) {
-    const int N = c->p.N, n = c->p.n, lg = c->p.l_gsw, lv = c->p.l_lev, rows = 2 * lg;
+/* n CMuxes of ONE RLWE sample acc = (mask, body), int64[2][N], with party's TGSW key: mux_rotate (J/bootstrap.jl:19-23) under
+   mk_single_blind_rotate (J/new_mk_internals.jl:226-238) and, per TLev sample, under mk_ith_blind_rotate (:210-223) */
+void oracle_kms_rlwe_rotate(const oracle_kms_ctx *c, int32_t party, const int32_t *bara, int64_t *acc, int use_schoolbook) {
+    const int N = c->p.N, n = c->p.n, lg = c->p.l_gsw, rows = 2 * lg;
     int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(2 + rows + 2 + 1) * N);
     int64_t *dig = tmp + 2 * (size_t)N, *ext = dig + (size_t)rows * N, *pr = ext + 2 * (size_t)N;
-    memset(lev, 0, sizeof(int64_t) * (size_t)lv * 2 * N);
-    for (int s = 0; s < lv; s++) lev[((size_t)s * 2 + 1) * N] = (int64_t)(1ull << (64 - (s + 1) * c->p.bg_lev)); /* body += 1 * gadget[s] */
     for (int j = 0; j < n; j++) {
         if (bara[j] == 0) continue;
         const int64_t *key = c->gsw + (((size_t)party * n + j) * rows) * 2 * N;
-        for (int s = 0; s < lv; s++) {
-            int64_t *acc = lev + (size_t)s * 2 * N;
-            for (int m = 0; m < 2; m++) {
-                oracle_mul_by_monomial64(acc + (size_t)m * N, bara[j], N, tmp + (size_t)m * N);
-                for (int q = 0; q < N; q++) tmp[(size_t)m * N + q] = (int64_t)((uint64_t)tmp[(size_t)m * N + q] - (uint64_t)acc[(size_t)m * N + q]);
-                oracle_decompose64(tmp + (size_t)m * N, N, lg, c->p.bg_gsw, dig + (size_t)m * lg * N);
-            }
-            memset(ext, 0, sizeof(int64_t) * 2 * (size_t)N);
-            for (int r = 0; r < rows; r++)
-                for (int col = 0; col < 2; col++) kms_mulacc(dig + (size_t)r * N, key + ((size_t)r * 2 + col) * N, N, ext + (size_t)col * N, 1, use_schoolbook, pr);
-            for (int q = 0; q < 2 * N; q++) acc[q] = (int64_t)((uint64_t)acc[q] + (uint64_t)ext[q]);
+        for (int m = 0; m < 2; m++) {
+            oracle_mul_by_monomial64(acc + (size_t)m * N, bara[j], N, tmp + (size_t)m * N);
+            for (int q = 0; q < N; q++) tmp[(size_t)m * N + q] = (int64_t)((uint64_t)tmp[(size_t)m * N + q] - (uint64_t)acc[(size_t)m * N + q]);
+            oracle_decompose64(tmp + (size_t)m * N, N, lg, c->p.bg_gsw, dig + (size_t)m * lg * N);
         }
+        memset(ext, 0, sizeof(int64_t) * 2 * (size_t)N);
+        for (int r = 0; r < rows; r++)
+            for (int col = 0; col < 2; col++) kms_mulacc(dig + (size_t)r * N, key + ((size_t)r * 2 + col) * N, N, ext + (size_t)col * N, 1, use_schoolbook, pr);
+        for (int q = 0; q < 2 * N; q++) acc[q] = (int64_t)((uint64_t)acc[q] + (uint64_t)ext[q]);
     }
     free(tmp);
+}
+void oracle_kms_tlev_rotate(const oracle_kms_ctx *c, int32_t party, const int32_t *bara, int64_t *lev, int use_schoolbook) {
+    const int N = c->p.N, lv = c->p.l_lev;
+    memset(lev, 0, sizeof(int64_t) * (size_t)lv * 2 * N);
+    for (int s = 0; s < lv; s++) {   /* tgsw_intern_mul (J/tlev.jl:88-95) works sample by sample: the l_lev rotations are independent */
+        lev[((size_t)s * 2 + 1) * N] = (int64_t)(1ull << (64 - (s + 1) * c->p.bg_lev)); /* body += 1 * gadget[s] */
+        oracle_kms_rlwe_rotate(c, party, bara, lev + (size_t)s * 2 * N, use_schoolbook);
+    }
 }
 
 /* UniProduct_new      J/new_mk_internals.jl:85-127.  e, out: int64[P+1][N] */
@@ -1272,7 +1277,10 @@ void oracle_kms_lev_rlwe_mul(const oracle_kms_ctx *c, int32_t party, int64_t *ac
 
 /* mk_bootstrap_wo_keyswitch_new (fast_boot = false): x int32[P*n+1] -> out int32[P*N+1]      J/new_mk_internals.jl:254-262,276-283,
  * 303-314; extraction mk_rlwe_extract_sample_64 :295-300 */
-void oracle_kms_bootstrap_wo_keyswitch(const oracle_kms_ctx *c, int64_t mu, const int32_t *x, int32_t *out, int use_schoolbook) {
+/* fast_boot = 0: mk_blind_rotate_and_extract_new (:271-283); fast_boot = 1: ..._new_v2 (:255-269, 286-291), which replaces the first
+   party's TLev rotation + relinearisation by ONE RLWE blind rotation (mask, body) of the test vector and accum = f - UniProduct_new(e),
+   e / f = the trivial multi-key samples of mask / body */
+void oracle_kms_bootstrap_wo_keyswitch_ex(const oracle_kms_ctx *c, int64_t mu, const int32_t *x, int32_t *out, int use_schoolbook, int fast_boot) {
     const int N = c->p.N, n = c->p.n, P = c->p.parties, lv = c->p.l_lev;
     int32_t barb = oracle_modswitch(x[(size_t)n * P], N);
     int64_t *accum = (int64_t *)calloc((size_t)(P + 1) * N + N + (size_t)lv * 2 * N, sizeof(int64_t));
@@ -1280,7 +1288,22 @@ void oracle_kms_bootstrap_wo_keyswitch(const oracle_kms_ctx *c, int64_t mu, cons
     int32_t *bara = (int32_t *)malloc(sizeof(int32_t) * n);
     for (int j = 0; j < N; j++) tv[j] = mu;
     oracle_mul_by_monomial64(tv, -barb, N, accum + (size_t)P * N);
-    for (int p = 0; p < P; p++) {
+    int first = 0;
+    if (fast_boot) {
+        int64_t *acc1 = (int64_t *)calloc(2 * (size_t)N + 2 * (size_t)(P + 1) * N, sizeof(int64_t));
+        int64_t *e = acc1 + 2 * (size_t)N, *up = e + (size_t)(P + 1) * N;
+        memcpy(acc1 + N, accum + (size_t)P * N, sizeof(int64_t) * N);     /* rlwe_noiseless_trivial(testvectbis) */
+        for (int j = 0; j < n; j++) bara[j] = oracle_modswitch(x[j], N);
+        oracle_kms_rlwe_rotate(c, 0, bara, acc1, use_schoolbook);
+        memcpy(e + (size_t)P * N, acc1, sizeof(int64_t) * N);              /* e = trivial(mask) */
+        oracle_kms_uniproduct(c, 0, e, up, use_schoolbook);
+        memset(accum, 0, sizeof(int64_t) * (size_t)(P + 1) * N);
+        memcpy(accum + (size_t)P * N, acc1 + N, sizeof(int64_t) * N);      /* f = trivial(body) */
+        for (size_t q = 0; q < (size_t)(P + 1) * N; q++) accum[q] = (int64_t)((uint64_t)accum[q] - (uint64_t)up[q]);
+        free(acc1);
+        first = 1;
+    }
+    for (int p = first; p < P; p++) {
         for (int j = 0; j < n; j++) bara[j] = oracle_modswitch(x[(size_t)p * n + j], N);
         oracle_kms_tlev_rotate(c, p, bara, lev, use_schoolbook);
         oracle_kms_lev_rlwe_mul(c, p, accum, lev, use_schoolbook);
@@ -1293,6 +1316,9 @@ void oracle_kms_bootstrap_wo_keyswitch(const oracle_kms_ctx *c, int64_t mu, cons
     out[(size_t)P * N] = oracle_t64tot32(accum[(size_t)P * N]);
     free(bara);
     free(accum);
+}
+void oracle_kms_bootstrap_wo_keyswitch(const oracle_kms_ctx *c, int64_t mu, const int32_t *x, int32_t *out, int use_schoolbook) {
+    oracle_kms_bootstrap_wo_keyswitch_ex(c, mu, x, out, use_schoolbook, 0);
 }
 /* mk_keyswitch (party p switches its own extracted mask)      J/mk_internals.jl:714-728 */
 void oracle_kms_keyswitch(const oracle_kms_ctx *c, const int32_t *in, int32_t *out) {
@@ -1309,7 +1335,8 @@ void oracle_kms_keyswitch(const oracle_kms_ctx *c, const int32_t *in, int32_t *o
     free(part);
 }
 /* mk_gate_nand_new (J/new_mk_gates.jl:1-7) and, on the same bootstrap, the other two-input linear prologues of J/gates.jl */
-int oracle_kms_gates(const oracle_kms_ctx *c, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count, int use_schoolbook) {
+int oracle_kms_gates_ex(const oracle_kms_ctx *c, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count, int use_schoolbook,
+                        int fast_boot) {
     const int n = c->p.n, N = c->p.N, P = c->p.parties;
     const size_t rec = (size_t)n * P + 1;
     lin_t L;
@@ -1321,11 +1348,14 @@ int oracle_kms_gates(const oracle_kms_ctx *c, int op, const int32_t *in0, const 
         const int32_t *x = in0 + g * rec, *y = in1 + g * rec;
         for (size_t q = 0; q < rec; q++) tmp[q] = (int32_t)((uint32_t)L.cx * (uint32_t)x[q] + (uint32_t)L.cy * (uint32_t)y[q]);
         tmp[rec - 1] = (int32_t)((uint32_t)tmp[rec - 1] + (uint32_t)L.cb);
-        oracle_kms_bootstrap_wo_keyswitch(c, (int64_t)1 << 61, tmp, u, use_schoolbook); /* encode_message64(1, 8) */
+        oracle_kms_bootstrap_wo_keyswitch_ex(c, (int64_t)1 << 61, tmp, u, use_schoolbook, fast_boot); /* encode_message64(1, 8) */
         oracle_kms_keyswitch(c, u, res + g * rec);
         free(tmp);
     }
     memcpy(out, res, sizeof(int32_t) * count * rec);
     free(res);
     return 0;
+}
+int oracle_kms_gates(const oracle_kms_ctx *c, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count, int use_schoolbook) {
+    return oracle_kms_gates_ex(c, op, in0, in1, out, count, use_schoolbook, 0);
 }

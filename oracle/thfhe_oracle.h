@@ -141,12 +141,16 @@ typedef struct oracle_kms_ctx oracle_kms_ctx;
 oracle_kms_ctx *oracle_kms_ctx_create(const oracle_kms_params *p, const int64_t *gsw, const int64_t *uni, const int64_t *pk, const int64_t *crs,
                                       const int32_t *ksk);
 void oracle_kms_ctx_destroy(oracle_kms_ctx *c);
+void oracle_kms_rlwe_rotate(const oracle_kms_ctx *c, int32_t party, const int32_t *bara, int64_t *acc /* [2][N] in/out */, int use_schoolbook);
 void oracle_kms_tlev_rotate(const oracle_kms_ctx *c, int32_t party, const int32_t *bara, int64_t *lev, int use_schoolbook);
 void oracle_kms_uniproduct(const oracle_kms_ctx *c, int32_t party, const int64_t *e, int64_t *out, int use_schoolbook);
 void oracle_kms_lev_rlwe_mul(const oracle_kms_ctx *c, int32_t party, int64_t *accum, const int64_t *lev, int use_schoolbook);
 void oracle_kms_bootstrap_wo_keyswitch(const oracle_kms_ctx *c, int64_t mu, const int32_t *x, int32_t *out, int use_schoolbook);
+void oracle_kms_bootstrap_wo_keyswitch_ex(const oracle_kms_ctx *c, int64_t mu, const int32_t *x, int32_t *out, int use_schoolbook, int fast_boot);
 void oracle_kms_keyswitch(const oracle_kms_ctx *c, const int32_t *in, int32_t *out);
 int oracle_kms_gates(const oracle_kms_ctx *c, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count, int use_schoolbook);
+int oracle_kms_gates_ex(const oracle_kms_ctx *c, int op, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count, int use_schoolbook,
+                        int fast_boot);   /* fast_boot: mk_blind_rotate_new_v2, J/new_mk_internals.jl:255-269 */
 
 int oracle_max_threads(void);
 void oracle_set_threads(int n); /* OpenMP team size for the batch entry points */

@@ -134,6 +134,9 @@ def lib():
         "oracle_kms_lev_rlwe_mul": (None, [vp, C.c_int32, i64p, i64p, C.c_int]),
         "oracle_kms_bootstrap_wo_keyswitch": (None, [vp, C.c_int64, i32p, i32p, C.c_int]),
         "oracle_kms_keyswitch": (None, [vp, i32p, i32p]),
+        "oracle_kms_rlwe_rotate": (None, [vp, C.c_int32, i32p, i64p, C.c_int]),
+        "oracle_kms_bootstrap_wo_keyswitch_ex": (None, [vp, C.c_int64, i32p, i32p, C.c_int, C.c_int]),
+        "oracle_kms_gates_ex": (C.c_int, [vp, C.c_int, i32p, i32p, i32p, C.c_size_t, C.c_int, C.c_int]),
         "oracle_kms_gates": (C.c_int, [vp, C.c_int, i32p, i32p, i32p, C.c_size_t, C.c_int]),
         "oracle_max_threads": (C.c_int, []),
         "oracle_set_threads": (None, [C.c_int]),
@@ -367,10 +370,21 @@ class KMSOracle:
             lib().oracle_kms_ctx_destroy(self.h)
             self.h = None
 
-    def gates(self, op, in0, in1, schoolbook=False):
+    def gates(self, op, in0, in1, schoolbook=False, fast_boot=False):
         in0, in1 = np.ascontiguousarray(in0, np.int32), np.ascontiguousarray(in1, np.int32)
         out = np.zeros_like(in0)
-        assert lib().oracle_kms_gates(self.h, op, p32(in0), p32(in1), p32(out), in0.shape[0], int(schoolbook)) == 0
+        assert lib().oracle_kms_gates_ex(self.h, op, p32(in0), p32(in1), p32(out), in0.shape[0], int(schoolbook), int(fast_boot)) == 0
+        return out
+
+    def rlwe_rotate(self, party, bara, acc, schoolbook=False):
+        acc = np.ascontiguousarray(acc, np.int64).copy()
+        lib().oracle_kms_rlwe_rotate(self.h, party, p32(np.ascontiguousarray(bara, np.int32)), p64(acc), int(schoolbook))
+        return acc
+
+    def uniproduct(self, party, e, schoolbook=False):
+        e = np.ascontiguousarray(e, np.int64)
+        out = np.zeros_like(e)
+        lib().oracle_kms_uniproduct(self.h, party, p64(e), p64(out), int(schoolbook))
         return out
 
     def tlev_rotate(self, party, bara, schoolbook=False):
@@ -384,10 +398,10 @@ class KMSOracle:
         lib().oracle_kms_lev_rlwe_mul(self.h, party, p64(accum), p64(np.ascontiguousarray(lev, np.int64)), int(schoolbook))
         return accum
 
-    def bootstrap_wo_keyswitch(self, x, mu=1 << 61, schoolbook=False):
+    def bootstrap_wo_keyswitch(self, x, mu=1 << 61, schoolbook=False, fast_boot=False):
         p = self.params
         out = np.zeros(p.parties * p.N + 1, np.int32)
-        lib().oracle_kms_bootstrap_wo_keyswitch(self.h, mu, p32(np.ascontiguousarray(x, np.int32)), p32(out), int(schoolbook))
+        lib().oracle_kms_bootstrap_wo_keyswitch_ex(self.h, mu, p32(np.ascontiguousarray(x, np.int32)), p32(out), int(schoolbook), int(fast_boot))
         return out
 
     def keyswitch(self, u):

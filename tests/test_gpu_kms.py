@@ -51,6 +51,15 @@ def test_kms_pieces_and_gates_bit_exact(O, name, n, parties):
     assert np.array_equal(out, orc.gates(O.NAND, ca, cb))
     assert np.array_equal(K.decrypt(out), ~(a.astype(bool) & b.astype(bool)))
     assert np.array_equal(ck.gates(O.XOR, ca, cb), orc.gates(O.XOR, ca, cb))
+    # fast_boot = true (mk_blind_rotate_new_v2, new_mk_internals.jl:255-269): one RLWE rotation for the first party
+    acc1 = rng.integers(-2**63, 2**63, size=(2, 2, p.N), dtype=np.int64)
+    rot = ck.rlwe_rotate(0, bar[:2, :n], acc1)
+    for g in range(2):
+        assert np.array_equal(rot[g], orc.rlwe_rotate(0, bar[g, :n], acc1[g])), (name, g)
+    fast = kms.mk_gate_nand_new(ck, ca, cb, fast_boot=True)
+    assert np.array_equal(fast, orc.gates(O.NAND, ca, cb, fast_boot=True))
+    assert np.array_equal(K.decrypt(fast), ~(a.astype(bool) & b.astype(bool)))
+    assert np.array_equal(kms.mk_bootstrap_new(ck, 1 << 61, ca[:1], fast_boot=True), ck.keyswitch(orc.bootstrap_wo_keyswitch(ca[0], fast_boot=True)[None]))
     ck.close()
 
 

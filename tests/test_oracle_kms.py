@@ -55,3 +55,34 @@ def test_kms_schoolbook_equals_ntt_and_pieces_compose(O):
     # the TLev accumulator of party i decrypts, under the party's fresh key, to gadget_l * X^{-<a_i, s_i>}: check through the final phase instead
     out = orc.keyswitch(u1)
     assert bool(K.decrypt(out[None])[0]) is True
+
+
+@pytest.mark.parametrize("name", ["KMS2", "KMS4"])
+def test_kms_fast_boot_truth_table_and_engines(O, name):
+    # fast_boot = true (mk_blind_rotate_new_v2, new_mk_internals.jl:255-269): the first party is ONE RLWE rotation of the test vector and
+    # accum = f - UniProduct_new(e); same truth table, a different ciphertext than the TLev route
+    p, K = make(n=5, N=1024, name=name)
+    orc = O.KMSOracle(p, K.gsw, K.uni, K.pk, K.crs, K.ksk)
+    a, b = np.array([0, 0, 1, 1]), np.array([0, 1, 0, 1])
+    xa, xb = K.encrypt(a, 11), K.encrypt(b, 12)
+    out = orc.gates(O.NAND, xa, xb, fast_boot=True)
+    assert np.array_equal(K.decrypt(out), ~(a.astype(bool) & b.astype(bool)))
+    assert np.abs(np.abs(K.phase(out).astype(np.float64) / 2.0**32) - 0.125).max() < 0.06
+    assert not np.array_equal(out, orc.gates(O.NAND, xa, xb))
+    assert np.array_equal(out[:2], orc.gates(O.NAND, xa[:2], xb[:2], schoolbook=True, fast_boot=True))
+    # composition of the exported pieces
+    N, P, n = p.N, p.parties, p.n
+    x = xa[2]
+    u = orc.bootstrap_wo_keyswitch(x, fast_boot=True)
+    barb = int(O.lib().oracle_modswitch(int(x[-1]), N))
+    acc1 = np.zeros((2, N), np.int64)
+    O.lib().oracle_mul_by_monomial64(O.p64(np.full(N, 1 << 61, np.int64)), -barb, N, O.p64(acc1[1]))
+    ms = lambda w: np.array([O.lib().oracle_modswitch(int(v), N) for v in w], np.int32)
+    acc1 = orc.rlwe_rotate(0, ms(x[:n]), acc1)
+    e, f = np.zeros((P + 1, N), np.int64), np.zeros((P + 1, N), np.int64)
+    e[P], f[P] = acc1[0], acc1[1]
+    accum = (f.view(np.uint64) - orc.uniproduct(0, e).view(np.uint64)).view(np.int64)
+    for party in range(1, P):
+        accum = orc.lev_rlwe_mul(party, accum, orc.tlev_rotate(party, ms(x[party * n:(party + 1) * n])))
+    t32 = lambda d: O.lib().oracle_t64tot32(int(d))
+    assert t32(accum[P, 0]) == u[P * N] and t32(accum[0, 0]) == u[0]

@@ -24,5 +24,10 @@ t0 = time.time()
 out = kms.mk_gate_nand_new(ck, xa, xb)
 dt = time.time() - t0
 ok = bool(np.array_equal(K.decrypt(out), ~(a.astype(bool) & b.astype(bool))))
+kms.mk_gate_nand_new(ck, xa[:4], xb[:4], fast_boot=True)
+t0 = time.time()
+outf = kms.mk_gate_nand_new(ck, xa, xb, fast_boot=True)      # mk_blind_rotate_new_v2: one RLWE rotation instead of the first party's TLev
+dtf = time.time() - t0
+okf = bool(np.array_equal(K.decrypt(outf), ~(a.astype(bool) & b.astype(bool))))
 print(json.dumps(dict(workload=f"{B} mk_gate_nand_new, {name} (P={p.parties}, n={p.n}, N={p.N}, gsw {p.l_gsw}/{p.bg_gsw}, lev {p.l_lev}/{p.bg_lev}, uni {p.l_uni}/{p.bg_uni})",
-                      gates_per_s=B / dt, seconds=dt, tlev_rotate_one_party_s=t_rot, host_keygen_s=t_key, all_decrypt_correct=ok)), flush=True)
+                      gates_per_s=B / dt, seconds=dt, fast_boot_gates_per_s=B / dtf, fast_boot_all_decrypt_correct=okf, tlev_rotate_one_party_s=t_rot, host_keygen_s=t_key, all_decrypt_correct=ok)), flush=True)

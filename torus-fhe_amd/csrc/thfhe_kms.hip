@@ -63,6 +63,7 @@ struct KmsBRArgs {
     const cplx *tw;
     const int32_t *bara;  // [gates][n]: the party's mod-switched mask words
     int64_t *acc_out;     // [gates * l_lev][2][2048]: TLev sample s of gate g at job g * l_lev + s
+    const int64_t *acc_in;  // null: TLev accumulators start at the trivial gadget samples; else one RLWE sample per gate (l_lev = 1) starts here
     long jobs;
     int n, lg, bg, parts, lo_bits, l_lev, bg_lev;
 };
@@ -85,9 +86,13 @@ __global__ __launch_bounds__(512, 2) void kms_tlev_rotate_kernel(KmsBRArgs a) {
     uint64_t offset = 0;
     for (int p = 1; p <= lg; p++) offset += (1ull << (bg - 1)) << (64 - p * bg);
     // tlev_trivial_int(levpar, lwepar, 1): mask 0, body = gadget value of level `sample` on the constant coefficient     (J/tlev.jl:37-66)
-    for (int q = threadIdx.x; q < 4096; q += 512) sAcc[q] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) sAcc[2048] = (int64_t)(1ull << (64 - (sample + 1) * a.bg_lev));
+    if (a.acc_in) {   // mk_single_blind_rotate (J/new_mk_internals.jl:226-238): the caller's RLWE sample
+        for (int q = threadIdx.x; q < 4096; q += 512) sAcc[q] = a.acc_in[job * 4096 + q];
+    } else {
+        for (int q = threadIdx.x; q < 4096; q += 512) sAcc[q] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) sAcc[2048] = (int64_t)(1ull << (64 - (sample + 1) * a.bg_lev));
+    }
     __syncthreads();
     const int o = wave >> 2, h = wave & 3;
     unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc) + o * 2048;
@@ -330,11 +335,31 @@ int thfhe_kms_tlev_rotate(thfhe_kms_ctx *c, int party, const int32_t *bara, int6
     if (!rc) rc = kms_ensure(c, 1, jobs * 4096 * sizeof(int64_t));
     if (rc) return rc;
     THFHE_HIP(hipMemcpyAsync(c->d_buf[0], bara, count * c->p.n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    KmsBRArgs a{c->d_bk + (size_t)party * c->party_stride, c->d_tw, (const int32_t *)c->d_buf[0], (int64_t *)c->d_buf[1], (long)jobs,
+    KmsBRArgs a{c->d_bk + (size_t)party * c->party_stride, c->d_tw, (const int32_t *)c->d_buf[0], (int64_t *)c->d_buf[1], nullptr, (long)jobs,
                 c->p.n, c->p.l_gsw, c->p.bg_gsw, c->parts, c->lo_bits, c->p.l_lev, c->p.bg_lev};
     hipLaunchKernelGGL(kms_tlev_rotate_kernel, dim3((unsigned)jobs), dim3(512), 0, c->stream, a);
     THFHE_HIP(hipGetLastError());
     THFHE_HIP(hipMemcpyAsync(lev, c->d_buf[1], jobs * 4096 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    return THFHE_OK;
+}
+
+int thfhe_kms_rlwe_rotate(thfhe_kms_ctx *c, int party, const int32_t *bara, int64_t *acc, size_t count) {
+    if (!c || !bara || !acc) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (party < 0 || party >= c->p.parties) return thfhe_fail(THFHE_E_INVALID, "party out of range");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    int rc = kms_ensure(c, 0, count * c->p.n * sizeof(int32_t));
+    if (!rc) rc = kms_ensure(c, 1, count * 4096 * sizeof(int64_t));
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(c->d_buf[0], bara, count * c->p.n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_buf[1], acc, count * 4096 * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    KmsBRArgs a{c->d_bk + (size_t)party * c->party_stride, c->d_tw, (const int32_t *)c->d_buf[0], (int64_t *)c->d_buf[1], (const int64_t *)c->d_buf[1],
+                (long)count, c->p.n, c->p.l_gsw, c->p.bg_gsw, c->parts, c->lo_bits, 1, c->p.bg_lev};   // in place: a workgroup reads its sample before it writes it
+    hipLaunchKernelGGL(kms_tlev_rotate_kernel, dim3((unsigned)count), dim3(512), 0, c->stream, a);
+    THFHE_HIP(hipGetLastError());
+    THFHE_HIP(hipMemcpyAsync(acc, c->d_buf[1], count * 4096 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     THFHE_HIP(hipStreamSynchronize(c->stream));
     return THFHE_OK;
 }

@@ -91,6 +91,14 @@ class KMSCloudKey:
         _check(lib().thfhe_kms_tlev_rotate(self.h, party, _p32(bara), lev.ctypes.data_as(_i64p), bara.shape[0]))
         return lev
 
+    def rlwe_rotate(self, party, bara, acc):
+        """mk_single_blind_rotate for a batch (new_mk_internals.jl:226-238): acc int64[count][2][N] (mask, body) -> rotated copy."""
+        p = self.params
+        bara = np.ascontiguousarray(bara, np.int32).reshape(-1, p.n)
+        acc = np.array(acc, np.int64, order="C").reshape(bara.shape[0], 2, p.N)
+        _check(lib().thfhe_kms_rlwe_rotate(self.h, party, _p32(bara), acc.ctypes.data_as(_i64p), bara.shape[0]))
+        return acc
+
     def lev_rlwe_mul(self, party, accum, lev):
         """mk_lev_rlwe_mul for a batch: accum int64[count][P+1][N] (a_0 .. a_{P-1}, b), lev int64[count][l_lev][2][N] -> new accum."""
         p, pm = self.params, self.pm
@@ -134,8 +142,9 @@ class KMSCloudKey:
         out[:, party] += w01[:, 1].view(np.uint64)                   # anew[party] += w1
         return out.view(np.int64)
 
-    def bootstrap_wo_keyswitch(self, x, mu=MU8_64):
-        """mk_bootstrap_wo_keyswitch_new, fast_boot = false (new_mk_internals.jl:303-314): int32[count][P n + 1] -> int32[count][P N + 1]."""
+    def bootstrap_wo_keyswitch(self, x, mu=MU8_64, fast_boot=False):
+        """mk_bootstrap_wo_keyswitch_new (new_mk_internals.jl:303-314): int32[count][P n + 1] -> int32[count][P N + 1].
+        fast_boot: mk_blind_rotate_new_v2 (:255-269) -- party 1 is ONE RLWE rotation of the test vector, accum = f - UniProduct_new(e)."""
         p = self.params
         P, N, n = p.parties, p.N, p.n
         x = _rec(x, self.words)
@@ -144,7 +153,18 @@ class KMSCloudKey:
         accum = np.zeros((G, P + 1, N), np.int64)
         k = (np.arange(N)[None, :] + bar[:, -1:].astype(np.int64)) % (2 * N)             # X^{-barb} (mu, ..., mu): coefficient q <- e = q + barb
         accum[:, P] = np.where(k >= N, -np.int64(mu), np.int64(mu))
-        for party in range(P):
+        first = 0
+        if fast_boot:
+            acc1 = np.zeros((G, 2, N), np.int64)
+            acc1[:, 1] = accum[:, P]                                  # rlwe_noiseless_trivial(testvectbis)
+            acc1 = self.rlwe_rotate(0, bar[:, :n], acc1)
+            e = np.zeros((G, P + 1, N), np.int64)
+            e[:, P] = acc1[:, 0]                                      # e = mk_rlwe_noiseless_trivial(mask), f = ...(body)
+            accum = np.zeros((G, P + 1, N), np.int64)
+            accum[:, P] = acc1[:, 1]
+            accum = (accum.view(np.uint64) - self.uniproduct(0, e).view(np.uint64)).view(np.int64)
+            first = 1
+        for party in range(first, P):
             lev = self.tlev_rotate(party, bar[:, party * n:(party + 1) * n])
             accum = self.lev_rlwe_mul(party, accum, lev)
         # mk_rlwe_extract_sample_64: a'_0 = a_0, a'_j = -a_{N-j} per party, b = body_0, each through t64tot32
@@ -162,10 +182,10 @@ class KMSCloudKey:
         _check(lib().thfhe_kms_keyswitch(self.h, _p32(u), _p32(out), u.shape[0]))
         return out
 
-    def bootstrap(self, x, mu=MU8_64):
-        return self.keyswitch(self.bootstrap_wo_keyswitch(x, mu))
+    def bootstrap(self, x, mu=MU8_64, fast_boot=False):
+        return self.keyswitch(self.bootstrap_wo_keyswitch(x, mu, fast_boot))
 
-    def gates(self, op, x, y):
+    def gates(self, op, x, y, fast_boot=False):
         """Two-input bootstrapped gates on MKLweSample batches; the reference defines the NAND (new_mk_gates.jl:1-7), the other linear
         prologues are those of gates.jl on the same bootstrap."""
         if op not in _LIN:
@@ -175,18 +195,14 @@ class KMSCloudKey:
         cb, cx, cy = _LIN[op]
         t = (cx * x.astype(np.int64) + cy * y.astype(np.int64))
         t[:, -1] += cb
-        return self.bootstrap(t.astype(np.uint32).view(np.int32))
+        return self.bootstrap(t.astype(np.uint32).view(np.int32), fast_boot=fast_boot)
 
 
 def mk_gate_nand_new(ck, x, y, fast_boot=False):
-    """new_mk_gates.jl:1-7.  fast_boot (the v2 rotation that skips the first party's TLev) is not implemented: it changes the noise, not the API."""
-    if fast_boot:
-        raise ThfheError("fast_boot = true (mk_blind_rotate_new_v2) is not implemented")
-    return ck.gates(NAND, x, y)
+    """new_mk_gates.jl:1-7; fast_boot selects mk_blind_rotate_new_v2 (the first party's TLev rotation replaced by one RLWE rotation)."""
+    return ck.gates(NAND, x, y, fast_boot=fast_boot)
 
 
 def mk_bootstrap_new(ck, mu, x, fast_boot=False):
     """new_mk_internals.jl:321-325 (bootstrap key and key-switch keys travel together in the KMSCloudKey)."""
-    if fast_boot:
-        raise ThfheError("fast_boot = true (mk_blind_rotate_new_v2) is not implemented")
-    return ck.bootstrap(x, mu)
+    return ck.bootstrap(x, mu, fast_boot=fast_boot)
