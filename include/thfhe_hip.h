@@ -223,7 +223,16 @@ int thfhe_pm_mac(thfhe_pm_ctx *ctx, const int32_t *small, size_t n_small, const 
  * thfhe_kms_rlwe_rotate   <- mk_single_blind_rotate (new_mk_internals.jl:226-238, the fast_boot route :255-269): acc int64[count][2][N]
  *                            (mask, body), rotated in place by the party's n TGSW-encrypted key bits
  * thfhe_kms_keyswitch     <- mk_keyswitch (mk_internals.jl:714-728): u int32[count][P N + 1] -> out int32[count][P n + 1]
- * The products between the two (tlev_extern_mul, UniProduct_new) go through thfhe_pm_mac under the host layer (thfhe/kms.py). */
+ * thfhe_kms_set_relin_keys <- the rest of MKBootstrapKey_new (mk_api.jl:440-455): uni int64[P][3][l_uni][N] (d, f0, f1 of every party's
+ *                            uni-encryption), pk int64[P][l_uni][N] (public keys), crs int64[l_uni][N] (shared key); transformed once
+ * thfhe_kms_lev_rlwe_mul  <- mk_lev_rlwe_mul (new_mk_internals.jl:185-207 = tlev_extern_mul + UniProduct_new :85-127): accum
+ *                            int64[count][P+1][N] (a_0 .. a_{P-1}, b) in place, lev int64[count][l_lev][2][N]
+ * thfhe_kms_bootstrap     <- mk_bootstrap_new (new_mk_internals.jl:315-325) / mk_bootstrap_wo_keyswitch_new (:302-313): x int32[count][P n+1]
+ *                            -> u int32[count][P N + 1] (before the key switch; may be null) and / or out int32[count][P n + 1] (may be null);
+ *                            fast_boot != 0 selects mk_blind_rotate_new_v2 (:255-269)
+ * thfhe_kms_gates         <- mk_gate_nand_new (new_mk_gates.jl:1-7) and the other two-input gates of gates.jl on the same bootstrap
+ * Between the gate's linear part and the key switch everything stays in HBM: prologue, per party the TLev rotation, gadget
+ * decompositions and exact polynomial multiply-accumulates of the relinearisation, extraction. */
 typedef struct {
     int32_t n, N, parties;
     int32_t l_gsw, bg_gsw;
@@ -237,6 +246,10 @@ void thfhe_kms_ctx_destroy(thfhe_kms_ctx *ctx);
 int thfhe_kms_tlev_rotate(thfhe_kms_ctx *ctx, int party, const int32_t *bara, int64_t *lev, size_t count);
 int thfhe_kms_rlwe_rotate(thfhe_kms_ctx *ctx, int party, const int32_t *bara, int64_t *acc, size_t count);
 int thfhe_kms_keyswitch(thfhe_kms_ctx *ctx, const int32_t *u, int32_t *out, size_t count);
+int thfhe_kms_set_relin_keys(thfhe_kms_ctx *ctx, const int64_t *uni, const int64_t *pk, const int64_t *crs);
+int thfhe_kms_lev_rlwe_mul(thfhe_kms_ctx *ctx, int party, int64_t *accum, const int64_t *lev, size_t count);
+int thfhe_kms_bootstrap(thfhe_kms_ctx *ctx, int64_t mu, const int32_t *x, int32_t *u, int32_t *out, size_t count, int fast_boot);
+int thfhe_kms_gates(thfhe_kms_ctx *ctx, int op, const int32_t *x, const int32_t *y, int32_t *out, size_t count, int fast_boot);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@
 //   thfhe_kms_keyswitch      mk_keyswitch: party p key-switches its own extracted mask (thfhe_mk_shared.h).
 #include <hip/hip_runtime.h>
 
+#include <deque>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -199,6 +200,85 @@ __global__ __launch_bounds__(512, 2) void kms_tlev_rotate_kernel(KmsBRArgs a) {
     for (int q = threadIdx.x; q < 4096; q += 512) a.acc_out[job * 4096 + q] = sAcc[q];
 }
 
+
+#include "thfhe_pm_kernels.h"
+
+// ---- device-resident mk_bootstrap_new: everything between the gate's linear part and the key switch stays in HBM -----------------
+// gate linear part (J/gates.jl, constants by opcode) + decode_message(., 2N) of every word + the accumulator X^{-barb} (mu, .., mu)
+// as a trivial multi-key RLWE sample (J/new_mk_internals.jl:271-276).  bara is party-major: [P][G][n].
+__global__ __launch_bounds__(256) void kms_prologue_kernel(const int32_t *__restrict__ x, const int32_t *__restrict__ y, int32_t cb, int32_t cx, int32_t cy,
+                                                            int n, int P, long G, int64_t mu, int32_t *__restrict__ bara, int64_t *__restrict__ accum) {
+    const long g = blockIdx.x;
+    const int words = P * n + 1;
+    __shared__ int s_barb;
+    auto word = [&](int q) {
+        uint32_t t = (uint32_t)cx * (uint32_t)x[g * words + q] + (y ? (uint32_t)cy * (uint32_t)y[g * words + q] : 0u);
+        if (q == words - 1) t += (uint32_t)cb;
+        return (int32_t)(t + (1u << 19)) >> 20;   // decode_message(t, 4096), J/numeric-functions.jl:70-73
+    };
+    for (int q = threadIdx.x; q < words; q += 256) {
+        const int32_t v = word(q);
+        if (q == words - 1) s_barb = v;
+        else bara[((size_t)(q / n) * G + g) * n + (q % n)] = v;
+    }
+    __syncthreads();
+    const int barb = s_barb;
+    int64_t *acc = accum + (size_t)g * (P + 1) * 2048;
+    for (int q = threadIdx.x; q < (P + 1) * 2048; q += 256) {
+        const int i = q >> 11, t = q & 2047;
+        acc[q] = i < P ? 0 : ((((t + barb) & 4095) >= 2048) ? -mu : mu);
+    }
+}
+// decompose (J/tgsw.jl:112-138, 64-bit words): polys[index[j]] -> digits out[j][level][2048], level 1 (most significant) first
+__global__ __launch_bounds__(256) void kms_decompose_kernel(const int64_t *__restrict__ polys, const int32_t *__restrict__ index, long n, int l, int bg,
+                                                             int32_t *__restrict__ out) {
+    const long j = blockIdx.x;
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    uint64_t offset = 0;
+    for (int p = 1; p <= l; p++) offset += (1ull << (bg - 1)) << (64 - p * bg);
+    const uint64_t v = (uint64_t)polys[(size_t)(index ? index[j] : j) * 2048 + q] + offset;
+    for (int p = 1; p <= l; p++) out[((size_t)j * l + (p - 1)) * 2048 + q] = (int32_t)((v >> (64 - p * bg)) & ((1ull << bg) - 1ull)) - (1 << (bg - 1));
+}
+// accum'[g][i] = (f - u)[g][pos[i]] (0 where polynomial i took no part), - w0 on the body, - w1 on the party's mask (J/new_mk_internals.jl:119-126,204-206)
+__global__ __launch_bounds__(256) void kms_assemble_kernel(const int64_t *__restrict__ r, const int64_t *__restrict__ w01, const int32_t *__restrict__ pos, int ns,
+                                                            int party, int P, int64_t *__restrict__ accum) {
+    const long g = blockIdx.x;
+    const int i = blockIdx.y;
+    const int ps = pos[i];
+    for (int q = threadIdx.x; q < 2048; q += 256) {
+        uint64_t v = ps >= 0 ? (uint64_t)r[((size_t)g * ns + ps) * 2048 + q] : 0ull;
+        if (i == P) v -= (uint64_t)w01[((size_t)g * 2 + 0) * 2048 + q];
+        if (i == party) v -= (uint64_t)w01[((size_t)g * 2 + 1) * 2048 + q];
+        accum[((size_t)g * (P + 1) + i) * 2048 + q] = (int64_t)v;
+    }
+}
+// mk_rlwe_extract_sample_64 + t64tot32 (J/new_mk_internals.jl:294-299): u[g] = (a'_0 .. a'_{P-1}, b), a'_p[0] = a_p[0], a'_p[j] = -a_p[N - j]
+__global__ __launch_bounds__(256) void kms_extract_kernel(const int64_t *__restrict__ accum, int P, int32_t *__restrict__ u) {
+    const long g = blockIdx.x;
+    const int p = blockIdx.y;
+    const int64_t *a = accum + ((size_t)g * (P + 1) + p) * 2048;
+    int32_t *dst = u + (size_t)g * (P * 2048 + 1) + (size_t)p * 2048;
+    if (p == P) {
+        if (threadIdx.x == 0) dst[0] = t64tot32(a[0]);
+        return;
+    }
+    for (int q = threadIdx.x; q < 2048; q += 256) dst[q] = t64tot32(q == 0 ? a[0] : (int64_t)(0ull - (uint64_t)a[2048 - q]));
+}
+// fast_boot: the first party's RLWE sample (0, testvect) in, its rotated (mask, body) out as e = mask, f = body
+__global__ __launch_bounds__(256) void kms_rlwe_init_kernel(const int64_t *__restrict__ accum, int P, int64_t *__restrict__ acc1) {
+    const long g = blockIdx.x;
+    for (int q = threadIdx.x; q < 2048; q += 256) {
+        acc1[(size_t)g * 4096 + q] = 0;
+        acc1[(size_t)g * 4096 + 2048 + q] = accum[((size_t)g * (P + 1) + P) * 2048 + q];
+    }
+}
+__global__ __launch_bounds__(256) void kms_rlwe_split_kernel(const int64_t *__restrict__ acc1, long G, int64_t *__restrict__ ef) {
+    const long g = blockIdx.x;
+    for (int q = threadIdx.x; q < 2048; q += 256) {
+        ef[(size_t)g * 2048 + q] = acc1[(size_t)g * 4096 + q];                  // e block [G][1][N]
+        ef[((size_t)G + g) * 2048 + q] = acc1[(size_t)g * 4096 + 2048 + q];   // f block
+    }
+}
 }  // namespace
 
 struct thfhe_kms_ctx {
@@ -212,6 +292,12 @@ struct thfhe_kms_ctx {
     size_t party_stride = 0;    // complex elements per party in d_bk
     void *d_buf[3] = {nullptr, nullptr, nullptr};
     size_t cap[3] = {0, 0, 0};
+    // relinearisation keys as limb spectra: [party][d | f0 | f1][l_uni], then pk [P][l_uni], then crs [l_uni]   (thfhe_kms_set_relin_keys)
+    cplx *d_relin = nullptr;
+    int *d_flag = nullptr;
+    enum { W_X, W_Y, W_BARA, W_ACCUM, W_LEV, W_LEVSPEC, W_SMALL, W_EF, W_R, W_V, W_W01, W_TERMS, W_FIRST, W_INDEX, W_U, W_OUT, W_ACC1, W_COUNT };
+    void *d_w[W_COUNT] = {};
+    size_t cap_w[W_COUNT] = {};
     std::mutex mu;
 };
 
@@ -320,6 +406,9 @@ void thfhe_kms_ctx_destroy(thfhe_kms_ctx *c) {
     (void)hipFree(c->d_bk);
     (void)hipFree(c->d_ksk);
     for (auto &q : c->d_buf) (void)hipFree(q);
+    for (auto &q : c->d_w) (void)hipFree(q);
+    (void)hipFree(c->d_relin);
+    (void)hipFree(c->d_flag);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -383,6 +472,281 @@ int thfhe_kms_keyswitch(thfhe_kms_ctx *c, const int32_t *u, int32_t *out, size_t
     THFHE_HIP(hipMemcpyAsync(out, c->d_buf[2], out_words * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     THFHE_HIP(hipStreamSynchronize(c->stream));
     return THFHE_OK;
+}
+
+}  // extern "C"
+
+namespace {
+int kms_w(thfhe_kms_ctx *c, int slot, size_t bytes) {
+    if (bytes <= c->cap_w[slot]) return THFHE_OK;
+    (void)hipFree(c->d_w[slot]);
+    c->d_w[slot] = nullptr;
+    c->cap_w[slot] = 0;
+    THFHE_HIP(hipMalloc(&c->d_w[slot], bytes));
+    c->cap_w[slot] = bytes;
+    return THFHE_OK;
+}
+// host-built tables of one call stay alive until the stream has been synchronised (asynchronous copies read them)
+struct KmsTables {
+    std::deque<std::vector<int32_t>> keep;   // a deque: references to earlier tables stay valid when one is added
+    std::vector<int32_t> &add() {
+        keep.emplace_back();
+        return keep.back();
+    }
+};
+// out[j] = addend[j] + sum_terms sign * small[s] (*) spec[t], all operands device-resident; terms = (out, small, torus, sign), ascending in out
+int kms_mac(thfhe_kms_ctx *c, KmsTables &tabs, const int32_t *d_small, const cplx *d_spec, std::vector<int32_t> &terms, size_t n_out, const void *d_addend,
+            void *d_out) {
+    std::vector<int32_t> &first = tabs.add();
+    first.assign(n_out + 1, 0);
+    const size_t n_terms = terms.size() / 4;
+    for (size_t t = 0; t < n_terms; t++) first[terms[4 * t] + 1]++;
+    for (size_t j = 0; j < n_out; j++) first[j + 1] += first[j];
+    int rc = kms_w(c, thfhe_kms_ctx::W_TERMS, (n_terms ? n_terms : 1) * 16);
+    if (!rc) rc = kms_w(c, thfhe_kms_ctx::W_FIRST, (n_out + 1) * 4);
+    if (rc) return rc;
+    if (n_terms) THFHE_HIP(hipMemcpyAsync(c->d_w[thfhe_kms_ctx::W_TERMS], terms.data(), n_terms * 16, hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_w[thfhe_kms_ctx::W_FIRST], first.data(), (n_out + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    PMArgs a{d_small, d_spec, (const int32_t *)c->d_w[thfhe_kms_ctx::W_TERMS], (const int32_t *)c->d_w[thfhe_kms_ctx::W_FIRST], d_addend, d_out, c->d_tw,
+             (long)n_out, c->d_flag};
+    hipLaunchKernelGGL((pm_mac_kernel<2048, 64>), dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, c->stream, a);
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+int kms_decompose(thfhe_kms_ctx *c, KmsTables &tabs, const int64_t *d_polys, const std::vector<int32_t> *index, size_t n, int l, int bg) {
+    int rc = kms_w(c, thfhe_kms_ctx::W_SMALL, n * l * 2048 * sizeof(int32_t));
+    if (rc) return rc;
+    const int32_t *d_index = nullptr;
+    if (index) {
+        rc = kms_w(c, thfhe_kms_ctx::W_INDEX, n * 4 + 64 * 4);
+        if (rc) return rc;
+        THFHE_HIP(hipMemcpyAsync(c->d_w[thfhe_kms_ctx::W_INDEX], index->data(), n * 4, hipMemcpyHostToDevice, c->stream));
+        d_index = (const int32_t *)c->d_w[thfhe_kms_ctx::W_INDEX];
+    }
+    hipLaunchKernelGGL(kms_decompose_kernel, dim3((unsigned)n, 8), dim3(256), 0, c->stream, d_polys, d_index, (long)n, l, bg, (int32_t *)c->d_w[thfhe_kms_ctx::W_SMALL]);
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+// UniProduct_new on e, accum' = f - (u, u0 + w0, a_party += w1)   (J/new_mk_internals.jl:85-127, 204-206).  d_ef = e block [G][ns][N] followed
+// by the f block; src[q] = which polynomial of the multi-key sample (0 .. P-1 masks, P body) row q is.
+int kms_relin_core(thfhe_kms_ctx *c, KmsTables &tabs, int party, size_t G, const std::vector<int> &src, int64_t *d_accum) {
+    typedef thfhe_kms_ctx K;
+    const int P = c->p.parties, lu = c->p.l_uni, ns = (int)src.size();
+    const size_t N = 2048, spec_poly = 4 * 1024;   // complex elements per torus polynomial (4 limbs x 2 halves x 512)
+    const int64_t *d_e = (const int64_t *)c->d_w[K::W_EF], *d_f = d_e + G * ns * N;
+    auto T_D = [&](int l) { return (party * 3 + 0) * lu + l; };
+    auto T_F = [&](int w, int l) { return (party * 3 + 1 + w) * lu + l; };
+    auto T_PK = [&](int i, int l) { return P * 3 * lu + i * lu + l; };
+    auto T_A = [&](int l) { return P * 3 * lu + P * lu + l; };
+    (void)spec_poly;
+    int rc = kms_decompose(c, tabs, d_e, nullptr, G * ns, lu, c->p.bg_uni);
+    if (!rc) rc = kms_w(c, K::W_R, G * ns * N * 8);
+    if (!rc) rc = kms_w(c, K::W_V, G * N * 8);
+    if (!rc) rc = kms_w(c, K::W_W01, G * 2 * N * 8);
+    if (rc) return rc;
+    const int32_t *d_small = (const int32_t *)c->d_w[K::W_SMALL];
+    std::vector<int32_t> &t_u = tabs.add(), &t_v = tabs.add(), &t_w = tabs.add();
+    for (size_t g = 0; g < G; g++)
+        for (int q = 0; q < ns; q++)
+            for (int l = 0; l < lu; l++) {
+                const int32_t j = (int32_t)(g * ns + q);
+                t_u.insert(t_u.end(), {j, j * lu + l, T_D(l), -1});          // (f - u)_q = f_q - sum_l dec(e_q)[l] (*) d[l]
+            }
+    for (size_t g = 0; g < G; g++)
+        for (int q = 0; q < ns; q++)
+            for (int l = 0; l < lu; l++) {
+                const int32_t sm = (int32_t)((g * ns + q) * lu + l);
+                if (src[q] < P) t_v.insert(t_v.end(), {(int32_t)g, sm, T_PK(src[q], l), 1});   // v = sum_i <dec(e_i), pk_i> - <dec(e_b), crs>
+                else t_v.insert(t_v.end(), {(int32_t)g, sm, T_A(l), -1});
+            }
+    rc = kms_mac(c, tabs, d_small, c->d_relin, t_u, G * ns, d_f, c->d_w[K::W_R]);
+    if (!rc) rc = kms_mac(c, tabs, d_small, c->d_relin, t_v, G, nullptr, c->d_w[K::W_V]);
+    if (!rc) rc = kms_decompose(c, tabs, (const int64_t *)c->d_w[K::W_V], nullptr, G, lu, c->p.bg_uni);   // stream order: after the two products read W_SMALL
+    if (rc) return rc;
+    for (size_t g = 0; g < G; g++)
+        for (int w = 0; w < 2; w++)
+            for (int l = 0; l < lu; l++) t_w.insert(t_w.end(), {(int32_t)(g * 2 + w), (int32_t)(g * lu + l), T_F(w, l), 1});   // w0 = <dec(v), f0>, w1 = <dec(v), f1>
+    rc = kms_mac(c, tabs, (const int32_t *)c->d_w[K::W_SMALL], c->d_relin, t_w, G * 2, nullptr, c->d_w[K::W_W01]);
+    if (rc) return rc;
+    std::vector<int32_t> &pos = tabs.add();
+    pos.assign(64, -1);
+    for (int q = 0; q < ns; q++) pos[src[q]] = q;
+    rc = kms_w(c, K::W_INDEX, (G * ns + 64) * 4);
+    if (rc) return rc;
+    int32_t *d_pos = (int32_t *)c->d_w[K::W_INDEX] + G * ns;   // behind the decompose index list of this step
+    THFHE_HIP(hipMemcpyAsync(d_pos, pos.data(), 64 * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(kms_assemble_kernel, dim3((unsigned)G, (unsigned)(P + 1)), dim3(256), 0, c->stream, (const int64_t *)c->d_w[K::W_R],
+                       (const int64_t *)c->d_w[K::W_W01], (const int32_t *)d_pos, ns, party, P, d_accum);
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+// mk_lev_rlwe_mul (J/new_mk_internals.jl:185-207): (e, f) = tlev_extern_mul of a_0 .. a_{party-1} and b with the TLev sample, then the core
+int kms_lev_rlwe_mul_dev(thfhe_kms_ctx *c, KmsTables &tabs, int party, size_t G, int64_t *d_accum, const int64_t *d_lev) {
+    typedef thfhe_kms_ctx K;
+    const int P = c->p.parties, lv = c->p.l_lev;
+    const size_t N = 2048;
+    std::vector<int> src;
+    for (int i = 0; i < party; i++) src.push_back(i);
+    src.push_back(P);
+    const int ns = (int)src.size();
+    std::vector<int32_t> &index = tabs.add(), &t1 = tabs.add();
+    for (size_t g = 0; g < G; g++)
+        for (int q = 0; q < ns; q++) index.push_back((int32_t)(g * (P + 1) + src[q]));
+    int rc = kms_decompose(c, tabs, d_accum, &index, G * ns, lv, c->p.bg_lev);
+    if (!rc) rc = kms_w(c, K::W_LEVSPEC, G * lv * 2 * 4 * 1024 * sizeof(cplx));
+    if (!rc) rc = kms_w(c, K::W_EF, 2 * G * ns * N * 8);
+    if (rc) return rc;
+    hipLaunchKernelGGL((pm_torus_transform_kernel<2048, 64>), dim3((unsigned)((G * lv * 2 * 4 + 3) / 4)), dim3(256), 0, c->stream, (const void *)d_lev,
+                       (long)(G * lv * 2), c->d_tw, (cplx *)c->d_w[K::W_LEVSPEC]);
+    THFHE_HIP(hipGetLastError());
+    for (int w = 0; w < 2; w++)   // e block (w = 0: masks of the TLev samples), then f block (w = 1: bodies)
+        for (size_t g = 0; g < G; g++)
+            for (int q = 0; q < ns; q++)
+                for (int s = 0; s < lv; s++)
+                    t1.insert(t1.end(), {(int32_t)((w * G + g) * ns + q), (int32_t)((g * ns + q) * lv + s), (int32_t)((g * lv + s) * 2 + w), 1});
+    rc = kms_mac(c, tabs, (const int32_t *)c->d_w[K::W_SMALL], (const cplx *)c->d_w[K::W_LEVSPEC], t1, 2 * G * ns, nullptr, c->d_w[K::W_EF]);
+    if (rc) return rc;
+    return kms_relin_core(c, tabs, party, G, src, d_accum);
+}
+int kms_launch_rotation(thfhe_kms_ctx *c, int party, const int32_t *d_bara, int64_t *d_out, const int64_t *d_in, size_t gates, int l_lev) {
+    KmsBRArgs a{c->d_bk + (size_t)party * c->party_stride, c->d_tw, d_bara, d_out, d_in, (long)(gates * l_lev),
+                c->p.n, c->p.l_gsw, c->p.bg_gsw, c->parts, c->lo_bits, l_lev, c->p.bg_lev};
+    hipLaunchKernelGGL(kms_tlev_rotate_kernel, dim3((unsigned)(gates * l_lev)), dim3(512), 0, c->stream, a);
+    THFHE_HIP(hipGetLastError());
+    return THFHE_OK;
+}
+int kms_finish(thfhe_kms_ctx *c) {
+    int flag = 0;
+    THFHE_HIP(hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    if (flag) return thfhe_fail(THFHE_E_UNSUPPORTED, "a gadget digit left [-4096, 4096] (outside the FP64 exactness bound of the relinearisation products)");
+    return THFHE_OK;
+}
+// the whole gate / bootstrap on device buffers; x (and y) int32[G][P n + 1] on the host
+int kms_bootstrap_impl(thfhe_kms_ctx *c, int32_t cb, int32_t cx, int32_t cy, int64_t mu, const int32_t *x, const int32_t *y, int32_t *u_out, int32_t *out,
+                       size_t G, int fast_boot) {
+    typedef thfhe_kms_ctx K;
+    if (!c->d_relin) return thfhe_fail(THFHE_E_INVALID, "thfhe_kms_set_relin_keys has not been called on this context");
+    const int P = c->p.parties, n = c->p.n, lv = c->p.l_lev;
+    const size_t N = 2048, words = (size_t)P * n + 1, uw = (size_t)P * N + 1;
+    std::lock_guard<std::mutex> lock(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    KmsTables tabs;
+    int rc = kms_w(c, K::W_X, G * words * 4);
+    if (!rc && y) rc = kms_w(c, K::W_Y, G * words * 4);
+    if (!rc) rc = kms_w(c, K::W_BARA, (size_t)P * G * n * 4);
+    if (!rc) rc = kms_w(c, K::W_ACCUM, G * (P + 1) * N * 8);
+    if (!rc) rc = kms_w(c, K::W_LEV, G * lv * 2 * N * 8);
+    if (!rc) rc = kms_w(c, K::W_U, G * uw * 4);
+    if (!rc) rc = kms_w(c, K::W_OUT, G * words * 4);
+    if (rc) return rc;
+    THFHE_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_w[K::W_X], x, G * words * 4, hipMemcpyHostToDevice, c->stream));
+    if (y) THFHE_HIP(hipMemcpyAsync(c->d_w[K::W_Y], y, G * words * 4, hipMemcpyHostToDevice, c->stream));
+    int64_t *d_accum = (int64_t *)c->d_w[K::W_ACCUM];
+    const int32_t *d_bara = (const int32_t *)c->d_w[K::W_BARA];
+    hipLaunchKernelGGL(kms_prologue_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, (const int32_t *)c->d_w[K::W_X], y ? (const int32_t *)c->d_w[K::W_Y] : nullptr,
+                       cb, cx, cy, n, P, (long)G, mu, (int32_t *)c->d_w[K::W_BARA], d_accum);
+    THFHE_HIP(hipGetLastError());
+    int first = 0;
+    if (fast_boot) {   // mk_blind_rotate_new_v2 (J/new_mk_internals.jl:255-269)
+        rc = kms_w(c, K::W_ACC1, G * 2 * N * 8);
+        if (!rc) rc = kms_w(c, K::W_EF, 2 * G * N * 8);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kms_rlwe_init_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, (const int64_t *)d_accum, P, (int64_t *)c->d_w[K::W_ACC1]);
+        rc = kms_launch_rotation(c, 0, d_bara, (int64_t *)c->d_w[K::W_ACC1], (const int64_t *)c->d_w[K::W_ACC1], G, 1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kms_rlwe_split_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, (const int64_t *)c->d_w[K::W_ACC1], (long)G, (int64_t *)c->d_w[K::W_EF]);
+        THFHE_HIP(hipGetLastError());
+        rc = kms_relin_core(c, tabs, 0, G, std::vector<int>{P}, d_accum);
+        if (rc) return rc;
+        first = 1;
+    }
+    for (int party = first; party < P; party++) {
+        rc = kms_launch_rotation(c, party, d_bara + (size_t)party * G * n, (int64_t *)c->d_w[K::W_LEV], nullptr, G, lv);
+        if (!rc) rc = kms_lev_rlwe_mul_dev(c, tabs, party, G, d_accum, (const int64_t *)c->d_w[K::W_LEV]);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kms_extract_kernel, dim3((unsigned)G, (unsigned)(P + 1)), dim3(256), 0, c->stream, (const int64_t *)d_accum, P, (int32_t *)c->d_w[K::W_U]);
+    THFHE_HIP(hipGetLastError());
+    if (u_out) THFHE_HIP(hipMemcpyAsync(u_out, c->d_w[K::W_U], G * uw * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out) {
+        THFHE_HIP(hipMemsetAsync(c->d_w[K::W_OUT], 0, G * words * 4, c->stream));
+        MKKSArgs k{c->d_ksk, (const int32_t *)c->d_w[K::W_U], (int32_t *)c->d_w[K::W_OUT], (long)G, n, c->p.ks_t, c->p.ks_basebit, P, c->row_words, (int)N,
+                   (int)uw, (int)N};
+        const int nsplit = G <= 64 ? 8 : 2;
+        hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)G, (unsigned)P, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
+        THFHE_HIP(hipGetLastError());
+        THFHE_HIP(hipMemcpyAsync(out, c->d_w[K::W_OUT], G * words * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    return kms_finish(c);
+}
+}  // namespace
+
+extern "C" {
+
+int thfhe_kms_set_relin_keys(thfhe_kms_ctx *c, const int64_t *uni, const int64_t *pk, const int64_t *crs) {
+    if (!c || !uni || !pk || !crs) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (c->p.l_uni < 1 || c->p.l_uni > 16 || c->p.bg_uni < 1 || c->p.bg_uni > 13 || c->p.l_uni * c->p.bg_uni > 64 || c->p.bg_lev > 13 || c->p.parties > 62)
+        return thfhe_fail(THFHE_E_UNSUPPORTED, "relinearisation gadgets: need Bgbit <= 13 (digits inside [-4096, 4096]), l_uni <= 16, l * Bgbit <= 64");
+    std::lock_guard<std::mutex> lock(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const int P = c->p.parties, lu = c->p.l_uni;
+    const size_t N = 2048, n_polys = (size_t)P * 3 * lu + (size_t)P * lu + lu;
+    void *d_raw = nullptr;
+    THFHE_HIP(hipMalloc(&d_raw, n_polys * N * 8));
+    hipError_t e = hipMemcpyAsync(d_raw, uni, (size_t)P * 3 * lu * N * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync((char *)d_raw + (size_t)P * 3 * lu * N * 8, pk, (size_t)P * lu * N * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync((char *)d_raw + (size_t)P * 4 * lu * N * 8, crs, (size_t)lu * N * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && !c->d_relin) e = hipMalloc(&c->d_relin, n_polys * 4 * 1024 * sizeof(cplx));
+    if (e == hipSuccess && !c->d_flag) e = hipMalloc(&c->d_flag, sizeof(int));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((pm_torus_transform_kernel<2048, 64>), dim3((unsigned)((n_polys * 4 + 3) / 4)), dim3(256), 0, c->stream, (const void *)d_raw, (long)n_polys,
+                           c->d_tw, c->d_relin);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_raw);
+    if (e != hipSuccess) return thfhe_fail_hip(e, "thfhe_kms_set_relin_keys");
+    return THFHE_OK;
+}
+
+int thfhe_kms_lev_rlwe_mul(thfhe_kms_ctx *c, int party, int64_t *accum, const int64_t *lev, size_t count) {
+    typedef thfhe_kms_ctx K;
+    if (!c || !accum || !lev) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (party < 0 || party >= c->p.parties) return thfhe_fail(THFHE_E_INVALID, "party out of range");
+    if (!c->d_relin) return thfhe_fail(THFHE_E_INVALID, "thfhe_kms_set_relin_keys has not been called on this context");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> lock(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t N = 2048, ab = count * (c->p.parties + 1) * N * 8, lb = count * c->p.l_lev * 2 * N * 8;
+    KmsTables tabs;
+    int rc = kms_w(c, K::W_ACCUM, ab);
+    if (!rc) rc = kms_w(c, K::W_LEV, lb);
+    if (rc) return rc;
+    THFHE_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_w[K::W_ACCUM], accum, ab, hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_w[K::W_LEV], lev, lb, hipMemcpyHostToDevice, c->stream));
+    rc = kms_lev_rlwe_mul_dev(c, tabs, party, count, (int64_t *)c->d_w[K::W_ACCUM], (const int64_t *)c->d_w[K::W_LEV]);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(accum, c->d_w[K::W_ACCUM], ab, hipMemcpyDeviceToHost, c->stream));
+    return kms_finish(c);
+}
+
+int thfhe_kms_bootstrap(thfhe_kms_ctx *c, int64_t mu, const int32_t *x, int32_t *u, int32_t *out, size_t count, int fast_boot) {
+    if (!c || !x || (!u && !out)) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (count == 0) return THFHE_OK;
+    return kms_bootstrap_impl(c, 0, 1, 0, mu, x, nullptr, u, out, count, fast_boot);
+}
+
+int thfhe_kms_gates(thfhe_kms_ctx *c, int op, const int32_t *x, const int32_t *y, int32_t *out, size_t count, int fast_boot) {
+    // J/gates.jl:15-161, (constant, coefficient of x, coefficient of y) by opcode THFHE_NAND .. THFHE_ORYN; mu = 1/8 on Torus64
+    static const int32_t lin[10][3] = {{1 << 29, -1, -1}, {1 << 29, 1, 1}, {-(1 << 29), 1, 1}, {1 << 30, 2, 2}, {-(1 << 30), -2, -2},
+                                       {-(1 << 29), -1, -1}, {-(1 << 29), -1, 1}, {-(1 << 29), 1, -1}, {1 << 29, -1, 1}, {1 << 29, 1, -1}};
+    if (!c || !x || !y || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    if (op < 0 || op > 9) return thfhe_fail(THFHE_E_UNSUPPORTED, "the KMS scheme evaluates two-input bootstrapped gates (opcodes NAND .. ORYN)");
+    if (count == 0) return THFHE_OK;
+    return kms_bootstrap_impl(c, lin[op][0], lin[op][1], lin[op][2], (int64_t)1 << 61, x, y, nullptr, out, count, fast_boot);
 }
 
 }  // extern "C"

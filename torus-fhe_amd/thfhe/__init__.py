@@ -124,6 +124,10 @@ SIGNATURES = {
     "thfhe_kms_ctx_destroy": (None, [_vp]),
     "thfhe_kms_tlev_rotate": (C.c_int, [_vp, C.c_int, _i32p, _i64p, C.c_size_t]),
     "thfhe_kms_rlwe_rotate": (C.c_int, [_vp, C.c_int, _i32p, _i64p, C.c_size_t]),
+    "thfhe_kms_set_relin_keys": (C.c_int, [_vp, _i64p, _i64p, _i64p]),
+    "thfhe_kms_lev_rlwe_mul": (C.c_int, [_vp, C.c_int, _i64p, _i64p, C.c_size_t]),
+    "thfhe_kms_bootstrap": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, _i32p, C.c_size_t, C.c_int]),
+    "thfhe_kms_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, C.c_size_t, C.c_int]),
     "thfhe_kms_keyswitch": (C.c_int, [_vp, _i32p, _i32p, C.c_size_t]),
     "thfhe_pm_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "thfhe_pm_ctx_destroy": (None, [_vp]),
