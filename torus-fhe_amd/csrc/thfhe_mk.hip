@@ -199,6 +199,26 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a
 // phase 1 (l = 2: one each), and the transpose scratch aliases the spectrum area (a third barrier frees it for the inverses), which is
 // what lets two accumulators and two sets of spectra fit: T1 8 + acc 32 + spectra 2 x 2l x 8 KiB (l = 3: 136 KiB).
 // ------------------------------------------------------------------------------------------------------
+// mk_pin: memory operations do not move across this point (keeps the paced key requests where they are written)
+__device__ __forceinline__ void mk_pin2() { asm volatile("" ::: "memory"); }
+// inverse transform of one partial spectrum with the requests for two key rows of the NEXT step between its stages
+template <bool PF0, bool PF1>
+__device__ __forceinline__ void inv_s_prefetch(int lane, cplx (&S)[8], cplx *xb, const cplx *T1, const W64 &w, cplx (&b0)[8], const cplx *src0, cplx (&b1)[8],
+                                               const cplx *src1) {
+    wave_sync();
+    invs_seg1(lane, S, xb, w);
+    mk_pin2();
+    if (PF0) load8(lane, b0, src0);
+    mk_pin2();
+    wave_sync();
+    invs_seg2_ld(lane, S, xb);
+    invs_seg2_st(lane, S, xb);
+    mk_pin2();
+    if (PF1) load8(lane, b1, src1);
+    mk_pin2();
+    wave_sync();
+    invs_seg3(lane, S, xb, T1);
+}
 template <int L>
 __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a) {
     constexpr int ROWS = 2 * L;
@@ -222,9 +242,23 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
     __syncthreads();
     const int o = wave >> 2, h = wave & 3;
 
-    for (int i = 0; i < a.pn; i++) {
-        const int ai0 = bara0[i], ai1 = has1 ? bara1[i] : 0;  // uniform over the workgroup
-        if (ai0 == 0 && ai1 == 0) continue;
+    // The first PRE key rows of a step are requested during the inverse transforms of the step before (the registers that held this
+    // step's rows are dead by then), between the stages of the transforms: the 8 PRE loads per wave stream in under ~8 k cycles of
+    // compute instead of queueing up in front of the multiply (256 KiB per workgroup and step at l = 2 are ~6 k cycles of the CU's
+    // vector-memory path).  Unconditional loads: the last step re-requests its own rows.
+    auto active = [&](int i) { return bara0[i] != 0 || (has1 && bara1[i] != 0); };   // uniform over the workgroup
+    int i = 0;
+    while (i < a.pn && !active(i)) i++;
+    cplx B[PRE][8];
+    if (i < a.pn) {
+#pragma unroll
+        for (int r = 0; r < PRE; r++) load8(lane, B[r], a.bk + mk_chunk_index(i, r, h, o, ROWS) * 512);
+    }
+    while (i < a.pn) {
+        const int ai0 = bara0[i], ai1 = has1 ? bara1[i] : 0;
+        int inext = i + 1;
+        while (inext < a.pn && !active(inext)) inext++;
+        const int inl = inext < a.pn ? inext : i;
 #pragma unroll
         for (int f0 = 0; f0 < FFTS; f0 += 8) {
             const int f = f0 + wave;  // forward-transform task: gate f / ROWS, digit row f % ROWS
@@ -244,9 +278,6 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
                 }
             }
         }
-        cplx B[PRE][8];
-#pragma unroll
-        for (int r = 0; r < PRE; r++) load8(lane, B[r], a.bk + mk_chunk_index(i, r, h, o, ROWS) * 512);
         __syncthreads();  // spectra published; every rotated read of the accumulators is done
         cplx S0[8], S1[8];
 #pragma unroll
@@ -264,31 +295,46 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
                 for (int m = 0; m < 8; m++) z[m] = sSpec[(ROWS + r) * 512 + m * 64 + lane];
                 mac8r(S1, z, B[r % PRE]);
             }
+            mk_pin2();
             if (r + PRE < ROWS) load8(lane, B[r % PRE], a.bk + mk_chunk_index(i, r + PRE, h, o, ROWS) * 512);
+            mk_pin2();
         }
         __syncthreads();  // spectra consumed: the area is transpose scratch from here on
         cplx *xb = sSpec + wave * 512;
+        const int ln = opaque_lane(lane);
+        const cplx *nx[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) nx[r] = a.bk + mk_chunk_index(inl, r < PRE ? r : 0, h, o, ROWS) * 512;
+        // gate 0's transform carries the requests for rows 0 / 1 of the next step, gate 1's those for rows 2 / 3 (PRE = 4); a skipped gate's
+        // requests are issued plainly so that B is complete whichever gates are active
         if (ai0 != 0) {
             unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[0]) + o * 1024;
-            wave_fft_inv_s(opaque_lane(lane), S0, xb, sT1, w64);
+            inv_s_prefetch<true, (PRE > 1)>(ln, S0, xb, sT1, w64, B[0], nx[0], B[PRE > 1 ? 1 : 0], nx[1]);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int q = lane + 64 * m;
                 atomicAdd(accu + q, (unsigned long long)round_i64(S0[m].re) << (16 * h));
                 atomicAdd(accu + q + 512, (unsigned long long)round_i64(S0[m].im) << (16 * h));
             }
+        } else {
+            load8(lane, B[0], nx[0]);
+            if (PRE > 1) load8(lane, B[PRE > 1 ? 1 : 0], nx[1]);
         }
         if (ai1 != 0) {
             unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[1]) + o * 1024;
-            wave_fft_inv_s(opaque_lane(lane), S1, xb, sT1, w64);
+            inv_s_prefetch<(PRE > 2), (PRE > 3)>(ln, S1, xb, sT1, w64, B[PRE > 2 ? 2 : 0], nx[2], B[PRE > 3 ? 3 : 0], nx[3]);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int q = lane + 64 * m;
                 atomicAdd(accu + q, (unsigned long long)round_i64(S1[m].re) << (16 * h));
                 atomicAdd(accu + q + 512, (unsigned long long)round_i64(S1[m].im) << (16 * h));
             }
+        } else {
+            if (PRE > 2) load8(lane, B[PRE > 2 ? 2 : 0], nx[2]);
+            if (PRE > 3) load8(lane, B[PRE > 3 ? 3 : 0], nx[3]);
         }
         __syncthreads();  // accumulators updated and scratch free before the next step
+        i = inext;
     }
     if (wave < 2 && (wave == 0 || has1)) extract16_64(lane, sAcc[wave], sAcc[wave] + 1024, a.out + (job0 + wave) * 1025);
 }
