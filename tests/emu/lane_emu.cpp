@@ -100,6 +100,24 @@ struct WaveQ {  // third-generation ring kernel: as WaveR, first transpose in re
         for (int l = 0; l < 64; l++) invq_seg3(z[l], base.r[l]);
     }
 };
+struct WaveQS {  // multi-key kernels: first transpose in registers, second through the XOR-swizzled 512-slot buffer (no room for padding)
+    WaveR base;
+    void fwd(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) fwdq_seg1(z[l], base.r[l]);
+        lanes_transpose_hi3(z);
+        for (int l = 0; l < 64; l++) fwds_seg2_st(l, z[l], base.xbuf, base.w[l]);
+        for (int l = 0; l < 64; l++) fwds_seg3(l, z[l], base.xbuf);
+    }
+    void inv(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) invs_seg1(l, z[l], base.xbuf, base.w[l]);
+        for (int l = 0; l < 64; l++) {
+            invs_seg2_ld(l, z[l], base.xbuf);
+            dft8<-1>(z[l]);
+        }
+        lanes_transpose_hi3(z);
+        for (int l = 0; l < 64; l++) invq_seg3(z[l], base.r[l]);
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -334,6 +352,9 @@ double emu_roots_variant_crosscheck(const int32_t *small, const int32_t *b, int3
 }
 double emu_regtranspose_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
     return variant_crosscheck<WaveQ>(small, b, out, dmax_out);
+}
+double emu_regtranspose_swizzled_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
+    return variant_crosscheck<WaveQS>(small, b, out, dmax_out);
 }
 }
 

@@ -102,13 +102,14 @@ def test_swizzled_variant_matches_padded(E, O):
     assert np.array_equal(ref, got) and d < 1e-9
 
 
-@pytest.mark.parametrize("fn", ["emu_roots_variant_crosscheck", "emu_regtranspose_variant_crosscheck"])
+@pytest.mark.parametrize("fn", ["emu_roots_variant_crosscheck", "emu_regtranspose_variant_crosscheck", "emu_regtranspose_swizzled_variant_crosscheck"])
 @pytest.mark.parametrize("case", ["random", "adversarial"])
 def test_roots_variant_exact_with_margin(E, O, case, fn):
     # second-generation ring kernel: pass-1 twiddles rebuilt from two per-lane roots (b * s^k0) instead of the T1 table.  The
     # products must stay exact with a wide margin, on random digits and on the worst case of the SK-80 shape (|digit| = 512,
     # every key word at +-2^31) where the limb sums are largest.
-    # (second variant: the same with the first transpose modelled as the in-register lane exchange of the third-generation kernel)
+    # (second variant: the same with the first transpose modelled as the in-register lane exchange of the third-generation kernel;
+    # third: that exchange followed by the XOR-swizzled second transpose, the combination the multi-key kernels use)
     getattr(E, fn).restype = C.c_double
     rng = np.random.default_rng(18)
     if case == "random":

@@ -187,6 +187,27 @@ __device__ __forceinline__ void wave_fft_inv_q(int lane, cplx (&z)[8], cplx *xb,
     wave_transpose_hi3(z);
     invq_seg3(z, r);
 }
+// variant "qs" (multi-key kernels, whose LDS has no room for padded buffers): first transpose in registers, pass-1 twiddles from the
+// per-lane roots, second transpose through the XOR-swizzled 512-slot buffer -- one LDS crossing and no T1 table reads per transform
+template <class Roots>
+__device__ __forceinline__ void wave_fft_fwd_qs(int lane, cplx (&z)[8], cplx *xb, const Roots &r, const W64 &w) {
+    fwdq_seg1(z, r);
+    wave_transpose_hi3(z);
+    wave_sync();
+    fwds_seg2_st(lane, z, xb, w);
+    wave_sync();
+    fwds_seg3(lane, z, xb);
+}
+template <class Roots>
+__device__ __forceinline__ void wave_fft_inv_qs(int lane, cplx (&z)[8], cplx *xb, const Roots &r, const W64 &w) {
+    wave_sync();
+    invs_seg1(lane, z, xb, w);
+    wave_sync();
+    invs_seg2_ld(lane, z, xb);
+    dft8<-1>(z);
+    wave_transpose_hi3(z);
+    invq_seg3(z, r);
+}
 // N = 2048 halves: twisted 512-point transforms (thfhe_lane.h, "N = 2048" section); T1t = the table of twist T
 template <int T>
 __device__ __forceinline__ void wave_fft_fwd_t(int lane, cplx (&z)[8], cplx *xb, const cplx *T1t, const W64 &w) {

@@ -197,14 +197,36 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop_kernel(MKBRArgs a
 // measured ~20 B/clk/CU, against ~5 k cycles of FP64 work).  Here every (output, limb) wave multiplies its key chunks into the
 // spectra of two gates, so each key byte serves two CMuxes; the 2 x 2l forward transforms of a step keep all eight waves busy in
 // phase 1 (l = 2: one each), and the transpose scratch aliases the spectrum area (a third barrier frees it for the inverses), which is
-// what lets two accumulators and two sets of spectra fit: T1 8 + acc 32 + spectra 2 x 2l x 8 KiB (l = 3: 136 KiB).
+// what lets two accumulators and two sets of spectra fit: acc 32 + spectra 2 x 2l x 8 KiB (l = 3: 128 KiB).  Transforms are variant "qs"
+// (first transpose in registers, pass-1 twiddles from per-lane roots: no T1 table, one LDS crossing per transform); measured on MI355X the
+// three ways of holding the pass-1 twiddles give MK2 39.5 k (hoisted by the compiler, 88 B/lane scratch) / 45.8 k (LaneTw, 48 B) /
+// 52.2 k gates/s (rebuilt per transform, 8 B): with four key rows carried across the loop the registers are worth more than 28 FP64
+// instructions per transform.
 // ------------------------------------------------------------------------------------------------------
 // mk_pin: memory operations do not move across this point (keeps the paced key requests where they are written)
 __device__ __forceinline__ void mk_pin2() { asm volatile("" ::: "memory"); }
 // inverse transform of one partial spectrum with the requests for two key rows of the NEXT step between its stages
+#ifndef THFHE_MK_LEAN_ROOTS
+#define THFHE_MK_LEAN_ROOTS 2
+#endif
+// pass-1 twiddles of the "qs" transforms: 0 = the compiler may hoist all eight products b s^k out of the CMux loop (32 VGPRs),
+// 1 = only the even ones live across the loop (LaneTw, 20 VGPRs), 2 = everything is rebuilt per transform from the two roots (8 VGPRs)
+#if THFHE_MK_LEAN_ROOTS == 1
+typedef LaneTw MK_ROOTS;
+__device__ __forceinline__ MK_ROOTS mk_make_roots(const LaneRoots &r) { return make_lane_tw(r); }
+__device__ __forceinline__ const MK_ROOTS &mk_use_roots(const MK_ROOTS &r) { return r; }
+#elif THFHE_MK_LEAN_ROOTS == 2
+typedef LaneRoots MK_ROOTS;
+__device__ __forceinline__ MK_ROOTS mk_make_roots(const LaneRoots &r) { return r; }
+__device__ __forceinline__ MK_ROOTS mk_use_roots(const MK_ROOTS &r) { return LaneRoots{opaque_cplx(r.b), opaque_cplx(r.s)}; }
+#else
+typedef LaneRoots MK_ROOTS;
+__device__ __forceinline__ MK_ROOTS mk_make_roots(const LaneRoots &r) { return r; }
+__device__ __forceinline__ const MK_ROOTS &mk_use_roots(const MK_ROOTS &r) { return r; }
+#endif
 template <bool PF0, bool PF1>
-__device__ __forceinline__ void inv_s_prefetch(int lane, cplx (&S)[8], cplx *xb, const cplx *T1, const W64 &w, cplx (&b0)[8], const cplx *src0, cplx (&b1)[8],
-                                               const cplx *src1) {
+__device__ __forceinline__ void inv_s_prefetch(int lane, cplx (&S)[8], cplx *xb, const MK_ROOTS &roots, const W64 &w, cplx (&b0)[8], const cplx *src0, cplx (&b1)[8],
+                                               const cplx *src1) {   // wave_fft_inv_qs with the requests in between
     wave_sync();
     invs_seg1(lane, S, xb, w);
     mk_pin2();
@@ -212,12 +234,12 @@ __device__ __forceinline__ void inv_s_prefetch(int lane, cplx (&S)[8], cplx *xb,
     mk_pin2();
     wave_sync();
     invs_seg2_ld(lane, S, xb);
-    invs_seg2_st(lane, S, xb);
+    dft8<-1>(S);
     mk_pin2();
     if (PF1) load8(lane, b1, src1);
     mk_pin2();
-    wave_sync();
-    invs_seg3(lane, S, xb, T1);
+    wave_transpose_hi3(S);
+    invq_seg3(S, mk_use_roots(roots));
 }
 template <int L>
 __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a) {
@@ -225,13 +247,13 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
     constexpr int FFTS = 2 * ROWS;
     constexpr int SPEC_SLOTS = (FFTS > 8 ? FFTS : 8) * 512;
     constexpr int PRE = ROWS <= 4 ? ROWS : 2;  // key rows in flight (32 VGPRs each)
-    __shared__ cplx sT1[512];
     __shared__ int64_t sAcc[2][2048];
     __shared__ cplx sSpec[SPEC_SLOTS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    sT1[threadIdx.x] = a.tw[threadIdx.x];
     const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
+    const LaneRoots roots0{a.tw[1088 + 2 * lane], a.tw[1088 + 2 * lane + 1]};
+    const MK_ROOTS roots = mk_make_roots(roots0);
     const long job0 = 2 * (long)blockIdx.x;
     const bool has1 = job0 + 1 < a.jobs;
     const int32_t *bara0 = a.bara + job0 * a.w_pad;
@@ -271,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
                     load_rotated16_hi(lane, sAcc[g] + (r / L) * 1024, ai & 2047, offset, t);
                     digits_to_z(t, (r % L) + 1, Bgbit, z);
                     cplx *slot = sSpec + f * 512;  // transposes run inside the task's own, not yet published, spectrum slot
-                    wave_fft_fwd_s(opaque_lane(lane), z, slot, sT1, w64);
+                    wave_fft_fwd_qs(opaque_lane(lane), z, slot, mk_use_roots(roots), w64);
                     wave_sync();
 #pragma unroll
                     for (int m = 0; m < 8; m++) slot[m * 64 + lane] = z[m];
@@ -309,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
         // requests are issued plainly so that B is complete whichever gates are active
         if (ai0 != 0) {
             unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[0]) + o * 1024;
-            inv_s_prefetch<true, (PRE > 1)>(ln, S0, xb, sT1, w64, B[0], nx[0], B[PRE > 1 ? 1 : 0], nx[1]);
+            inv_s_prefetch<true, (PRE > 1)>(ln, S0, xb, roots, w64, B[0], nx[0], B[PRE > 1 ? 1 : 0], nx[1]);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int q = lane + 64 * m;
@@ -322,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
         }
         if (ai1 != 0) {
             unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[1]) + o * 1024;
-            inv_s_prefetch<(PRE > 2), (PRE > 3)>(ln, S1, xb, sT1, w64, B[PRE > 2 ? 2 : 0], nx[2], B[PRE > 3 ? 3 : 0], nx[3]);
+            inv_s_prefetch<(PRE > 2), (PRE > 3)>(ln, S1, xb, roots, w64, B[PRE > 2 ? 2 : 0], nx[2], B[PRE > 3 ? 3 : 0], nx[3]);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int q = lane + 64 * m;
@@ -726,7 +748,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto &e : c->ev) CK(hipEventCreate(&e));
-    std::vector<cplx> tw(1088);  // N = 1024: T1[512] T2[64]; N = 2048: T1(twist 1)[512] T1(twist 5)[512] T2[64]
+    std::vector<cplx> tw(1088 + 128);  // N = 1024: T1[512] T2[64]; N = 2048: T1(twist 1)[512] T1(twist 5)[512] T2[64]; [1088..): per-lane roots (N = 1024)
     if (p->N == 2048) {
         std::vector<cplx> unused(512);
         make_twiddles_2048(tw.data(), tw.data() + 512);
@@ -734,6 +756,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     } else {
         make_twiddles_1024(tw.data(), tw.data() + 512);
     }
+    make_lane_roots_1024(tw.data() + 1088);
     CK(hipMalloc(&c->d_tw, tw.size() * sizeof(cplx)));
     CK(hipMemcpyAsync(c->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
     const long PN = (long)p->parties * p->n;
