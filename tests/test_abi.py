@@ -37,6 +37,22 @@ def test_library_exports_every_declared_symbol():
     assert set(thfhe.SIGNATURES) == declared_symbols("thfhe_hip.h")
 
 
+def test_julia_layer_binds_existing_symbols_with_matching_arity():
+    # Julia is not installed in the build image: what can be checked without it is that every ccall of torus-fhe_amd/julia/TFHE_HIP.jl names a
+    # symbol the library exports and passes as many arguments as the C prototype (and the Python binding) declares
+    import thfhe
+    L = thfhe.lib()
+    src = open(os.path.join(ROOT, "torus-fhe_amd", "julia", "TFHE_HIP.jl")).read()
+    calls = re.findall(r"ccall\(\(:([A-Za-z0-9_]+), LIB\), *[A-Za-z]+, *\(([^()]*(?:\{[^()]*\}[^()]*)*)\)", src)
+    assert len(calls) >= 20
+    for name, argtypes in calls:
+        assert hasattr(L, name), name
+        n_jl = len([a for a in argtypes.split(",") if a.strip()])
+        if name in thfhe.SIGNATURES:
+            assert n_jl == len(thfhe.SIGNATURES[name][1]), (name, n_jl, len(thfhe.SIGNATURES[name][1]))
+    assert {"thfhe_kms_gates", "thfhe_kms_bootstrap", "thfhe_kms_set_relin_keys", "thfhe_pm_mac"} <= {c[0] for c in calls}
+
+
 def test_params_struct_layout():
     import thfhe
     assert C.sizeof(thfhe.Params) == 36

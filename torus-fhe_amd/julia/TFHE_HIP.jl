@@ -11,7 +11,8 @@ export HipCloudKey, HipMKCloudKey, gate_nand, gate_or, gate_and, gate_xor, gate_
        gate_orny, gate_oryn, gate_mux, gate_not, bootstrap, bootstrap_wo_keyswitch, keyswitch,
        mk_gate_nand_3gen, mk_gate_or_3gen, mk_gate_and_3gen, mk_gate_xor_3gen, mk_gate_3and_3gen, mk_gate_mux_3gen,
        mk_gate_not_3gen, mk_bootstrap_3gen, HipCCSCloudKey, mk_gate_nand, mk_bootstrap, dag_run,
-       HipPolyContext, TLweFromLwe, PartialDecrypt, finalDecrypt
+       HipPolyContext, TLweFromLwe, PartialDecrypt, finalDecrypt,
+       KmsParams, HipKMSCloudKey, mk_gate_nand_new, mk_bootstrap_new, mk_bootstrap_wo_keyswitch_new, HipPolyMac, poly_mac
 
 const LIB = get(ENV, "THFHE_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libthfhe_hip.so"))
 
@@ -206,6 +207,66 @@ function finalDecrypt(c::HipPolyContext, b::Matrix{Int32}, partials::Array{Int32
     check(ccall((:thfhe_final_decrypt, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Cint, Ptr{Int32}, Ptr{Int32}, Csize_t),
                 c.h, b, partials, size(partials, 3), C_NULL, bits, size(b, 2)))
     bits .> 0
+end
+
+# ---- KMS multi-key scheme (new_mk_gates.jl:1-7, new_mk_internals.jl:302-325) -----------------------------------------------------------
+struct KmsParams                   # thfhe_kms_params
+    n::Int32; N::Int32; parties::Int32
+    l_gsw::Int32; bg_gsw::Int32
+    l_lev::Int32; bg_lev::Int32
+    l_uni::Int32; bg_uni::Int32
+    ks_t::Int32; ks_basebit::Int32
+end
+mutable struct HipKMSCloudKey      # MKCloudKey_new (mk_api.jl:440-455) on the device
+    h::Ptr{Cvoid}
+    p::KmsParams
+end
+# gsw Int64[N, 2, 2 l_gsw, n, P] (TGswSample rows before the forward transform), uni Int64[N, l_uni, 3, P] (d, f0, f1), pk Int64[N, l_uni, P],
+# crs Int64[N, l_uni], ksk Int32[n+1, base-1, t, N, P] -- Julia's column-major order of these shapes is the C order the ABI expects
+function HipKMSCloudKey(p::KmsParams, gsw::Array{Int64}, uni::Array{Int64}, pk::Array{Int64}, crs::Array{Int64}, ksk::Array{Int32}; device::Integer=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:thfhe_kms_ctx_create, LIB), Cint, (Ref{KmsParams}, Ptr{Int64}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}), p, gsw, ksk, device, h))
+    ck = HipKMSCloudKey(h[], p)
+    finalizer(c -> ccall((:thfhe_kms_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.h), ck)
+    check(ccall((:thfhe_kms_set_relin_keys, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), ck.h, uni, pk, crs))
+    ck
+end
+# x, y: (P n + 1, count) columns (vec(sample.a); sample.b)
+function mk_gate_nand_new(ck::HipKMSCloudKey, x::Matrix{Int32}, y::Matrix{Int32}, fast_boot::Bool=false)      # new_mk_gates.jl:1-7
+    out = similar(x)
+    check(ccall((:thfhe_kms_gates, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Csize_t, Cint), ck.h, NAND, x, y, out, size(x, 2), fast_boot))
+    out
+end
+function mk_bootstrap_new(ck::HipKMSCloudKey, mu::Int64, x::Matrix{Int32}, fast_boot::Bool=false)               # new_mk_internals.jl:315-325
+    out = similar(x)
+    check(ccall((:thfhe_kms_bootstrap, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Csize_t, Cint), ck.h, mu, x, C_NULL, out, size(x, 2), fast_boot))
+    out
+end
+function mk_bootstrap_wo_keyswitch_new(ck::HipKMSCloudKey, mu::Int64, x::Matrix{Int32}, fast_boot::Bool=false)  # new_mk_internals.jl:302-313
+    u = Matrix{Int32}(undef, ck.p.parties * ck.p.N + 1, size(x, 2))
+    check(ccall((:thfhe_kms_bootstrap, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Csize_t, Cint), ck.h, mu, x, u, C_NULL, size(x, 2), fast_boot))
+    u
+end
+
+# ---- exact small x torus polynomial multiply-accumulate (the products of multi-key key generation, multikey_3gen.jl:15-30) ------------
+mutable struct HipPolyMac
+    h::Ptr{Cvoid}
+    N::Int
+    bits::Int
+end
+function HipPolyMac(N::Integer, torus_bits::Integer; device::Integer=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:thfhe_pm_ctx_create, LIB), Cint, (Cint, Cint, Cint, Ref{Ptr{Cvoid}}), device, N, torus_bits, h))
+    c = HipPolyMac(h[], N, torus_bits)
+    finalizer(x -> ccall((:thfhe_pm_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), c)
+    c
+end
+# out[:, j] = addend[:, j] + sum over the columns (j, s, t, sign) of `terms` (0-based, ascending in j) of sign * small[:, s] (*) torus[:, t]
+function poly_mac(c::HipPolyMac, small::Matrix{Int32}, torus::Matrix{T}, terms::Matrix{Int32}, n_out::Integer, addend::Union{Nothing, Matrix{T}}=nothing) where {T<:Union{Int32, Int64}}
+    out = Matrix{T}(undef, c.N, n_out)
+    GC.@preserve addend check(ccall((:thfhe_pm_mac, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Csize_t, Ptr{Cvoid}, Csize_t, Ptr{Int32}, Csize_t, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+        c.h, small, size(small, 2), torus, size(torus, 2), terms, size(terms, 2), addend === nothing ? C_NULL : pointer(addend), out, n_out))
+    out
 end
 
 end # module
