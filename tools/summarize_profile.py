@@ -63,8 +63,10 @@ def main():
     os.makedirs(P, exist_ok=True)
 
     def find(pattern):
+        # gpurun merges a run's files INTO the local gpurun_out/, next to those of earlier runs with the same tag (rocprofv3 names its
+        # csv files by process id): take the newest match, never an older run's
         r = glob.glob(os.path.join(G, pattern), recursive=True)
-        return r[0] if r else None
+        return max(r, key=os.path.getmtime) if r else None
 
     bench_line = None
     tj = os.path.join(G, f"{tag}_trace.json")
