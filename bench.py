@@ -178,8 +178,10 @@ def main():
     p = thfhe.make_params(args.set)
     mk = p.torus_bits == 64
     if mk:   # 3-gen multi-key (BASELINE.json configs[2], [4]); noise per J/mk_api.jl:32-38,84-90
-        lwe_sigma = {"MK2": 2.0**-13.52, "MK3": 2.0**-13.26, "MK4": 2.0**-13.26, "MK4-N2048": 2.0**-13.26}.get(args.set, 2.0**-13.52)
-        K = keygen.MKSecretKeySet(p, seed=0x5EED0001, sigma_lwe=lwe_sigma, sigma_bk=2.0**-30.70)
+        lwe_sigma = {"MK2": 2.0**-13.52, "MK3": 2.0**-13.26, "MK4": 2.0**-13.26, "MK4-N2048": 2.0**-13.26, "MK16": 2.0**-15.34, "MK32": 2.0**-16.12,
+                     "MK64": 2.0**-16.90, "MK128": 2.0**-17.42}.get(args.set, 2.0**-13.52)
+        wide = p.Bgbit > 10   # the 16+-party sets (J/mk_api.jl:214-298): one level, 24 .. 26-bit base, RLWE noise 2^-62; keys generated on the device
+        K = keygen.MKSecretKeySet(p, seed=0x5EED0001, sigma_lwe=lwe_sigma, sigma_bk=2.0**-62 if wide else 2.0**-30.70, device=device if wide else None)
         ck = thfhe.MKCloudKey(p, K.bk, K.ksk, device=device)
     else:    # SURVEY.md section 8(d) synthetic-input recipe
         sig = dict(lwe=2.0**-15, bk=2.0**-25, ks=2.0**-15)

@@ -529,7 +529,10 @@ struct oracle_mk_ctx {
     oracle_params p;
     const int64_t *bk;
     const int32_t *ksk;
-    uint64_t *bk_lo, *bk_hi; /* NTT of the two 32-bit limbs of every BK polynomial */
+    /* NTT of the limbs of every BK polynomial: two 32-bit limbs, or four 16-bit limbs when the digits are so wide (the l = 1, Bgbit 24-27
+     * sets of 16+ parties, J/mk_api.jl:214-296) that a digit x 32-bit-limb sum would leave the +-p/2 range of the exact NTT product */
+    int limbs, limb_bits;
+    uint64_t *bk_limb[4];
 };
 
 oracle_mk_ctx *oracle_mk_ctx_create(const oracle_params *p, const int64_t *bk, const int32_t *ksk) {
@@ -541,25 +544,32 @@ oracle_mk_ctx *oracle_mk_ctx_create(const oracle_params *p, const int64_t *bk, c
     const int N = p->N;
     const gl_tables *T = gl_get_tables(N);
     size_t polys = (size_t)p->parties * p->n * 4 * p->l;
-    c->bk_lo = (uint64_t *)malloc(polys * N * sizeof(uint64_t));
-    c->bk_hi = (uint64_t *)malloc(polys * N * sizeof(uint64_t));
+    /* |sum| <= 2 l N 2^(Bgbit-1) 2^limb_bits must stay below 2^62 */
+    int lg = 0;
+    while ((1 << lg) < 2 * p->l * N) lg++;
+    c->limb_bits = (lg + p->Bgbit - 1 + 32 <= 62) ? 32 : 16;
+    c->limbs = 64 / c->limb_bits;
+    if (lg + p->Bgbit - 1 + c->limb_bits > 62) {
+        free(c);
+        return NULL;
+    }
+    for (int h = 0; h < c->limbs; h++) c->bk_limb[h] = (uint64_t *)malloc(polys * N * sizeof(uint64_t));
 #pragma omp parallel for schedule(static)
     for (long q = 0; q < (long)polys; q++) {
-        uint64_t *lo = c->bk_lo + (size_t)q * N, *hi = c->bk_hi + (size_t)q * N;
         const int64_t *src = bk + (size_t)q * N;
-        for (int j = 0; j < N; j++) {
-            lo[j] = (uint64_t)src[j] & 0xFFFFFFFFull;
-            hi[j] = gl_from_i64(src[j] >> 32);
+        for (int h = 0; h < c->limbs; h++) {
+            uint64_t *dst = c->bk_limb[h] + (size_t)q * N;
+            const int sh = h * c->limb_bits;
+            for (int j = 0; j < N; j++)   /* the top limb is signed, the others unsigned: v = sum_h limb_h 2^(h limb_bits) */
+                dst[j] = h == c->limbs - 1 ? gl_from_i64(src[j] >> sh) : (((uint64_t)src[j] >> sh) & ((1ull << c->limb_bits) - 1ull));
+            gl_ntt_fwd(dst, T);
         }
-        gl_ntt_fwd(lo, T);
-        gl_ntt_fwd(hi, T);
     }
     return c;
 }
 void oracle_mk_ctx_destroy(oracle_mk_ctx *c) {
     if (!c) return;
-    free(c->bk_lo);
-    free(c->bk_hi);
+    for (int h = 0; h < 4; h++) free(c->bk_limb[h]);
     free(c);
 }
 
@@ -587,29 +597,30 @@ static void mk_extern_mul(const oracle_mk_ctx *c, int party, int i, const int64_
                 }
     } else {
         const gl_tables *T = gl_get_tables(N);
-        uint64_t *d = (uint64_t *)scr(SCR_MKEXT_NTT, sizeof(uint64_t) * (2 * (size_t)l + 2) * N);
-        uint64_t *alo = d + 2 * (size_t)l * N, *ahi = alo + N;
+        uint64_t *d = (uint64_t *)scr(SCR_MKEXT_NTT, sizeof(uint64_t) * (2 * (size_t)l + 4) * N);
+        uint64_t *al = d + 2 * (size_t)l * N;   /* one sum per key limb */
+        const int H = c->limbs;
         for (int r = 0; r < 2 * l; r++) {
             for (int j = 0; j < N; j++) d[(size_t)r * N + j] = gl_from_i64(dig[(size_t)r * N + j]);
             gl_ntt_fwd(d + (size_t)r * N, T);
         }
         for (int o = 0; o < 2; o++) {
             for (int j = 0; j < N; j++) {
-                uint64_t slo = 0, shi = 0;
+                uint64_t sum[4] = {0, 0, 0, 0};
                 for (int w = 0; w < 2; w++)
                     for (int q = 0; q < l; q++) {
                         uint64_t dv = d[((size_t)(w == 0 ? l : 0) + q) * N + j]; /* g_c0 stored second */
                         size_t ro = (key_off + (size_t)part_for[o][w] * l + q) * N + j;
-                        slo = gl_add(slo, gl_mul(dv, c->bk_lo[ro]));
-                        shi = gl_add(shi, gl_mul(dv, c->bk_hi[ro]));
+                        for (int h = 0; h < H; h++) sum[h] = gl_add(sum[h], gl_mul(dv, c->bk_limb[h][ro]));
                     }
-                alo[j] = slo;
-                ahi[j] = shi;
+                for (int h = 0; h < H; h++) al[(size_t)h * N + j] = sum[h];
             }
-            gl_ntt_inv(alo, T);
-            gl_ntt_inv(ahi, T);
-            for (int j = 0; j < N; j++)
-                out[(size_t)o * N + j] = (int64_t)((uint64_t)gl_to_centered(alo[j]) + ((uint64_t)gl_to_centered(ahi[j]) << 32));
+            for (int h = 0; h < H; h++) gl_ntt_inv(al + (size_t)h * N, T);
+            for (int j = 0; j < N; j++) {
+                uint64_t v = 0;
+                for (int h = 0; h < H; h++) v += (uint64_t)gl_to_centered(al[(size_t)h * N + j]) << (h * c->limb_bits);
+                out[(size_t)o * N + j] = (int64_t)v;
+            }
         }
     }
 }

@@ -44,6 +44,11 @@ PARAM_SETS = {
     "MK5": dict(n=520, N=1024, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=5),   # mk_api.jl:98-104
     "MK8": dict(n=540, N=1024, k=1, l=4, Bgbit=4, ks_t=5, ks_basebit=2, torus_bits=64, parties=8),   # mk_api.jl:140-146
     "MK4-N2048": dict(n=510, N=2048, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
+    # the 16 .. 128-party 3-gen sets: ring degree 2048, ONE decomposition level with a 24 .. 26-bit base (mk_api.jl:214-220, 246-252, 268-274, 292-298)
+    "MK16": dict(n=590, N=2048, k=1, l=1, Bgbit=26, ks_t=4, ks_basebit=3, torus_bits=64, parties=16),
+    "MK32": dict(n=620, N=2048, k=1, l=1, Bgbit=26, ks_t=4, ks_basebit=3, torus_bits=64, parties=32),
+    "MK64": dict(n=650, N=2048, k=1, l=1, Bgbit=25, ks_t=4, ks_basebit=3, torus_bits=64, parties=64),
+    "MK128": dict(n=670, N=2048, k=1, l=1, Bgbit=24, ks_t=5, ks_basebit=3, torus_bits=64, parties=128),
     # CCS scheme (mk_bootstrap / mk_gate_nand): mktfhe_parameters_2party / _4party, J/mk_api.jl:4-10,56-62
     "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
     "CCS4": dict(n=560, N=1024, k=1, l=4, Bgbit=8, ks_t=8, ks_basebit=2, torus_bits=32, parties=4),
@@ -60,6 +65,10 @@ SIGMAS = {
     "MK5": dict(lwe=2.0 ** -13.52, bk=2.0 ** -30.70, ks=2.0 ** -13.52),
     "MK8": dict(lwe=2.0 ** -14.04, bk=2.0 ** -30.70, ks=2.0 ** -14.04),
     "MK4-N2048": dict(lwe=2.0 ** -13.26, bk=2.0 ** -30.70, ks=2.0 ** -13.26),
+    "MK16": dict(lwe=2.0 ** -15.34, bk=2.0 ** -62.0, ks=2.0 ** -15.34),
+    "MK32": dict(lwe=2.0 ** -16.12, bk=2.0 ** -62.0, ks=2.0 ** -16.12),
+    "MK64": dict(lwe=2.0 ** -16.90, bk=2.0 ** -62.0, ks=2.0 ** -16.90),
+    "MK128": dict(lwe=2.0 ** -17.42, bk=2.0 ** -62.0, ks=2.0 ** -17.42),
     "CCS2": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS4": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
 }

@@ -136,6 +136,26 @@ def test_mk_n2048_reduced_n_all_gates_bit_exact(O):
         ck.close()
 
 
+@pytest.mark.parametrize("name,n,parties", [("MK16", 12, 3), ("MK64", 9, 2), ("MK128", 10, 2)])
+def test_mk_wide_base_16_plus_party_sets_bit_exact(O, name, n, parties):
+    # mktfhe_parameters_{16,32,64,128}party_3gen (J/mk_api.jl:214-298): N = 2048, ONE level with a 26 / 25 / 24-bit base.  A 26-bit digit times a
+    # 16-bit key limb is outside the FP64 exactness bound, so the kernel cuts every digit into three balanced parts of 9 / 9 / 8 bit and
+    # multiplies part w into the key row shifted left by 9 w bits (three copies in the key table): six row parts, the l = 3 shape.
+    # Gadgets, ring and key-switch shape of the reference sets, LWE dimension and party count reduced to keep the oracle in seconds.
+    import thfhe
+    p = O.make_params(name, n=n, parties=parties)
+    s = O.SIGMAS[name]
+    K = O.MKKeys(p, 83, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    ck = thfhe.MKCloudKey(thfhe.make_params(**p.as_dict()), K.bk, K.ksk, device=0)
+    a = np.array([0, 0, 1, 1, 1]); b = np.array([0, 1, 0, 1, 1]); c = np.array([1, 0, 1, 0, 0])
+    ca, cb, cc = (K.encrypt_bits(v, s["lwe"], 50 + q) for q, v in enumerate((a, b, c)))
+    for op, args in ((O.NAND, (ca, cb)), (O.XOR, (ca, cb)), (O.AND3, (ca, cb, cc)), (O.MUX, (ca, cb, cc))):
+        assert np.array_equal(ck.gates(op, *args), orc.gates(op, *args)), (name, op)
+    assert np.array_equal(K.decrypt_bits(ck.gates(thfhe.NAND, ca, cb)), ~(a.astype(bool) & b.astype(bool)))
+    ck.close()
+
+
 def test_mk4_n2048_full_size(O):
     # BASELINE configs[4]: 4 parties, N = 2048, l = 3 at the reference's 4-party LWE dimension (n = 510)
     import thfhe

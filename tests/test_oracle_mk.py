@@ -107,3 +107,25 @@ def test_mk_product_keygen_decrypts(O):
     a = np.array([0, 1, 1, 0]); b = np.array([1, 1, 0, 0])
     out = orc.gates(O.NAND, MK.encrypt(a, 1), MK.encrypt(b, 2))
     assert np.array_equal(MK.decrypt(out), ~(a.astype(bool) & b.astype(bool)))
+
+
+def test_mk_wide_base_sets_16_plus_parties(O):
+    # the 16 .. 128-party 3-gen sets use ONE decomposition level with a 24 .. 26-bit base on the ring of degree 2048 (mk_api.jl:214-298):
+    # a digit (2^25) times a 32-bit key limb summed over 2 l N terms leaves the exact range of the NTT product, so the oracle switches to
+    # four 16-bit limbs; schoolbook (wrapping, always exact) and NTT engines must agree, and the gates must decrypt.  Reduced n and P.
+    p = O.make_params("MK16", n=5, parties=3)
+    s = O.SIGMAS["MK16"]
+    K = O.MKKeys(p, 77, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    a, b = np.array([0, 0, 1, 1]), np.array([0, 1, 0, 1])
+    ca, cb = K.encrypt_bits(a, s["lwe"], 5), K.encrypt_bits(b, s["lwe"], 6)
+    out = orc.gates(O.NAND, ca, cb)
+    assert np.array_equal(out[:2], orc.gates(O.NAND, ca[:2], cb[:2], schoolbook=True))
+    assert np.array_equal(K.decrypt_bits(out), ~(a.astype(bool) & b.astype(bool)))
+    assert np.abs(np.abs(K.phases(out) / 2.0**32) - 0.125).max() < 0.06
+    p24 = O.make_params("MK128", n=4, parties=2)
+    K24 = O.MKKeys(p24, 78, 2.0**-62, 2.0**-17.42)
+    o24 = O.MKOracle(p24, K24.bk, K24.ksk)
+    c1, c2 = K24.encrypt_bits([1, 0], 2.0**-17.42, 1), K24.encrypt_bits([1, 1], 2.0**-17.42, 2)
+    r = o24.gates(O.XOR, c1, c2)
+    assert np.array_equal(r, o24.gates(O.XOR, c1, c2, schoolbook=True)) and np.array_equal(K24.decrypt_bits(r), [False, True])

@@ -59,6 +59,16 @@ __global__ __launch_bounds__(256) void mk_key_transform_kernel(const int64_t *__
     }
 }
 
+// wide gadget base: src [poly = (pi, part_q, level)][2048] -> dst [(pi, part_q, level * parts + w)][2048] = src << (pw w)
+__global__ __launch_bounds__(256) void mk_expand_parts_kernel(const int64_t *__restrict__ src, int64_t *__restrict__ dst, int l, int parts, int pw) {
+    const long poly = blockIdx.x;   // (pi * 4 + q) * l + level
+    const int w = blockIdx.y;
+    const long head = poly / l, level = poly % l;
+    const int64_t *s = src + poly * 2048;
+    int64_t *d = dst + ((head * l + level) * parts + w) * 2048;
+    for (int t = threadIdx.x; t < 2048; t += 256) d[t] = (int64_t)((uint64_t)s[t] << (pw * w));
+}
+
 // N = 2048: one wave per (pi, row, output, limb); two twisted 512-point spectra (even / odd outputs) per item, scaled by 1/1024
 __global__ __launch_bounds__(256) void mk_key_transform_2k_kernel(const int64_t *__restrict__ bk, long PN, int l,
                                                                    const cplx *__restrict__ tw, cplx *__restrict__ spec) {
@@ -106,6 +116,9 @@ struct MKBRArgs {
     // initialised / extracted here.  acc_in == nullptr: start from X^{-barb} * mu; acc_out == nullptr: extract into `out`.
     const int64_t *acc_in = nullptr;
     int64_t *acc_out = nullptr;
+    // N = 2048, wide gadget base (the 16+-party sets: l = 1, Bgbit 24 .. 26): every digit is cut into `parts` balanced parts of `pw` bits,
+    // d = sum_w d_w 2^(pw w); part w multiplies the key row shifted left by pw w bits (a second / third copy in the key table)
+    int parts = 1, pw = 0;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -371,9 +384,11 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
 THFHE_STAMP_STORAGE
 __device__ __forceinline__ void mk_pin() { asm volatile("" ::: "memory"); }  // memory operations do not move across this point
 
-template <int L>
+template <int LE>   // LE = l x parts: digit rows per accumulator polynomial
 __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs a) {
-    constexpr int ROWS = 2 * L;
+    constexpr int ROWS = 2 * LE;
+    const int parts = a.parts > 1 ? a.parts : 1, pw = a.pw;
+    const int L = LE / parts;   // decomposition levels
     constexpr int SPEC_SLOTS = ROWS * 1024 > 8 * 512 ? ROWS * 1024 : 8 * 512;
     __shared__ cplx sT1[2][512];
     __shared__ int64_t sAcc[4096];
@@ -419,10 +434,12 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
             {
                 // digits of the four coefficients (j, j + 512, j + 1024, j + 1536) that make one (y0[m], y1[m]) pair: no 32-word t[],
                 // no 16-point z[] alive next to the two half transforms
-                const int64_t *ap = sAcc + (wave / L) * 2048;
-                const int shift = 32 - ((wave % L) + 1) * Bgbit;
+                const int64_t *ap = sAcc + (wave / LE) * 2048;
+                const int level = (wave % LE) / parts, part = (wave % LE) % parts;   // uniform per wave
+                const int shift = 32 - (level + 1) * Bgbit;
                 const uint32_t mask = (1u << Bgbit) - 1u;
                 const int32_t half = 1 << (Bgbit - 1);
+                const int32_t hp = pw ? 1 << (pw - 1) : 0, mp = (1 << pw) - 1;
                 constexpr double R = 0.70710678118654752440;
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
@@ -430,7 +447,12 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const uint32_t t = (uint32_t)((rot_minus_self64_n<2048>(ap, lane + 64 * m + 512 * q, a2n) + offset) >> 32);
-                        d[q] = digit32(t, shift, mask, half);
+                        int32_t dg = (int32_t)((t >> shift) & mask) - half;      // decompose, J/tgsw.jl:112-138
+                        if (parts > 1) {                                            // balanced parts, least significant first
+                            for (int w = 0; w < part; w++) dg = (dg - (((dg + hp) & mp) - hp)) >> pw;
+                            if (part < parts - 1) dg = ((dg + hp) & mp) - hp;
+                        }
+                        d[q] = (double)dg;
                     }
                     // z[m] = (d0, d2) (coefficients j, j + 1024), z[m + 8] = (d1, d3); split2048: y0/1 = z[m] +- e^{i pi/4} z[m + 8]
                     const cplx w{(d[1] - d[3]) * R, (d[1] + d[3]) * R};
@@ -540,6 +562,7 @@ struct thfhe_mk_ctx {
     cplx *d_tw = nullptr;
     int row_words = 0, w_pad = 0, words = 0, log2_2n = 11;
     long pair_threshold = 256;  // batches of more rotations than this run two gates per workgroup (mk_blind_rotate_pair_kernel)
+    int parts = 1, pw = 0;      // N = 2048 with a wide gadget base: digit parts and their width (MKBRArgs)
     size_t cap_jobs = 0;
     int32_t *d_bara = nullptr, *d_barb = nullptr, *d_u = nullptr, *d_tmp = nullptr;
     size_t cap_stage = 0;
@@ -613,11 +636,14 @@ int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1,
 int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a) {
     const dim3 grid((unsigned)a.jobs), block(512);
     if (c->p.N == 2048) {
-        switch (c->p.l) {
-        case 1: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<1>, grid, block, 0, c->stream, a); break;
-        case 2: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<2>, grid, block, 0, c->stream, a); break;
-        case 3: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<3>, grid, block, 0, c->stream, a); break;
-        default: return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 2048 needs decomposition length l <= 3");
+        MKBRArgs b = a;
+        b.parts = c->parts;
+        b.pw = c->pw;
+        switch (c->p.l * c->parts) {
+        case 1: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<1>, grid, block, 0, c->stream, b); break;
+        case 2: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<2>, grid, block, 0, c->stream, b); break;
+        case 3: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<3>, grid, block, 0, c->stream, b); break;
+        default: return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 2048 needs l x digit parts <= 3");
         }
         THFHE_HIP(hipGetLastError());
         return THFHE_OK;
@@ -715,9 +741,13 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     if (p->torus_bits != 64) return thfhe_fail(THFHE_E_UNSUPPORTED, "thfhe_mk_ctx_create is the Torus64 3-gen multi-key path");
     if ((p->N != 1024 && p->N != 2048) || p->k != 1) return thfhe_fail(THFHE_E_UNSUPPORTED, "only N = 1024 / 2048, k = 1 is implemented");
     if (p->N == 2048 && p->l > 3) return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 2048 needs decomposition length l <= 3");
-    if (p->parties < 1 || p->parties > 16) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= parties <= 16");
-    if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || p->Bgbit > 10 || p->l * p->Bgbit > 32)
-        return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 4, Bgbit <= 10 (FP64 exactness bound), l*Bgbit <= 32");
+    if (p->parties < 1 || p->parties > 128) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= parties <= 128");
+    // digits beyond 10 bit are cut into balanced parts of <= 9 bit (N = 2048 only: the sets that use a wide base live on that ring,
+    // J/mk_api.jl:214-298); |sum| <= 2 l parts N 2^(pw-1) 2^15 <= 2^36.6 stays inside the N = 2048 exactness bound
+    const int parts = p->Bgbit > 10 ? (p->Bgbit + 8) / 9 : 1;
+    const int pw = parts > 1 ? (p->Bgbit + parts - 1) / parts : 0;
+    if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || p->l * p->Bgbit > 32 || (parts > 1 && (p->N != 2048 || p->l * parts > 3)))
+        return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 4, l*Bgbit <= 32, and Bgbit <= 10 (FP64 exactness bound) unless N = 2048 with l x ceil(Bgbit / 9) <= 3");
     if (p->n < 1 || p->n > 767) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= n <= 767");
     if (p->ks_t < 1 || p->ks_basebit < 1 || p->ks_t * p->ks_basebit > 31) return thfhe_fail(THFHE_E_INVALID, "bad key-switch parameters");
     int ndev = 0;
@@ -732,6 +762,8 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     c->w_pad = (c->words + 3) & ~3;
     c->row_words = 128 * ((p->n + 1 + 127) / 128);
     c->log2_2n = ilog2(2 * p->N);
+    c->parts = parts;
+    c->pw = pw;
     int64_t *d_coeff = nullptr;  // upload staging, freed on every path
     int32_t *d_raw = nullptr;
     auto fail = [&](int code) {
@@ -763,11 +795,22 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     const size_t coeff_words = (size_t)PN * 4 * p->l * p->N;
     CK(hipMalloc(&d_coeff, coeff_words * sizeof(int64_t)));
     CK(hipMemcpyAsync(d_coeff, bk_coeff, coeff_words * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-    const size_t chunks = (size_t)PN * 2 * p->l * 8;
+    const int le = p->l * parts;
+    const size_t chunks = (size_t)PN * 2 * le * 8;
     CK(hipMalloc(&c->d_bk, chunks * (p->N / 2) * sizeof(cplx)));
     if (p->N == 2048) {
-        const long items = PN * 2 * p->l * 8;
-        hipLaunchKernelGGL(mk_key_transform_2k_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, c->stream, d_coeff, PN, p->l, c->d_tw, c->d_bk);
+        if (parts > 1) {   // key rows followed by their copies shifted left by pw, 2 pw bits (wrapping): d (*) K = sum_w d_w (*) (K << pw w)
+            int64_t *d_exp = nullptr;
+            CK(hipMalloc(&d_exp, coeff_words * parts * sizeof(int64_t)));
+            const long polys = PN * 4 * p->l;
+            hipLaunchKernelGGL(mk_expand_parts_kernel, dim3((unsigned)polys, (unsigned)parts), dim3(256), 0, c->stream, d_coeff, d_exp, p->l, parts, pw);
+            CK(hipGetLastError());
+            CK(hipStreamSynchronize(c->stream));
+            (void)hipFree(d_coeff);
+            d_coeff = d_exp;
+        }
+        const long items = PN * 2 * le * 8;
+        hipLaunchKernelGGL(mk_key_transform_2k_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, c->stream, d_coeff, PN, le, c->d_tw, c->d_bk);
     } else {
         const long items = PN * 2 * p->l * 2;
         hipLaunchKernelGGL(mk_key_transform_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, c->stream, d_coeff, PN, p->l, c->d_tw, c->d_bk);

@@ -46,6 +46,11 @@ PARAM_SETS = {
     "MK8": dict(n=540, N=1024, k=1, l=4, Bgbit=4, ks_t=5, ks_basebit=2, torus_bits=64, parties=8),   # mk_api.jl:140-146
     # BASELINE.json configs[4] wording ("4-party 3-gen MK-TFHE, N=2048 l=3"): the reference's 4-party set on the larger ring
     "MK4-N2048": dict(n=510, N=2048, k=1, l=3, Bgbit=6, ks_t=5, ks_basebit=2, torus_bits=64, parties=4),
+    # the 16 .. 128-party 3-gen sets: ring degree 2048, ONE decomposition level with a 24 .. 26-bit base (mk_api.jl:214-220, 246-252, 268-274, 292-298)
+    "MK16": dict(n=590, N=2048, k=1, l=1, Bgbit=26, ks_t=4, ks_basebit=3, torus_bits=64, parties=16),
+    "MK32": dict(n=620, N=2048, k=1, l=1, Bgbit=26, ks_t=4, ks_basebit=3, torus_bits=64, parties=32),
+    "MK64": dict(n=650, N=2048, k=1, l=1, Bgbit=25, ks_t=4, ks_basebit=3, torus_bits=64, parties=64),
+    "MK128": dict(n=670, N=2048, k=1, l=1, Bgbit=24, ks_t=5, ks_basebit=3, torus_bits=64, parties=128),
     # CCS scheme (mk_bootstrap / mk_gate_nand): mktfhe_parameters_2party / _4party, mk_api.jl:4-10,56-62
     "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
     "CCS4": dict(n=560, N=1024, k=1, l=4, Bgbit=8, ks_t=8, ks_basebit=2, torus_bits=32, parties=4),
