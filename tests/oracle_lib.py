@@ -52,6 +52,7 @@ PARAM_SETS = {
     # CCS scheme (mk_bootstrap / mk_gate_nand): mktfhe_parameters_2party / _4party, J/mk_api.jl:4-10,56-62
     "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
     "CCS4": dict(n=560, N=1024, k=1, l=4, Bgbit=8, ks_t=8, ks_basebit=2, torus_bits=32, parties=4),
+    "CCS8": dict(n=560, N=1024, k=1, l=5, Bgbit=6, ks_t=8, ks_basebit=2, torus_bits=32, parties=8),   # mktfhe_parameters_8party, mk_api.jl:111-117
 }
 # noise standard deviations (torus units): J/api.jl:101-115 (SK-128: 2^-15 / 2^-25 per src/libthfhe.cpp:325-326),
 # J/mk_api.jl:32-38 (MK2), :84-90 (MK4)
@@ -71,6 +72,7 @@ SIGMAS = {
     "MK128": dict(lwe=2.0 ** -17.42, bk=2.0 ** -62.0, ks=2.0 ** -17.42),
     "CCS2": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS4": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
+    "CCS8": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
 }
 
 

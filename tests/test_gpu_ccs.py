@@ -20,7 +20,8 @@ def make(O, name, **over):
 @pytest.mark.parametrize("name,over", [("CCS2", dict(n=20)),                                   # l = 3: batches of 2 + 1 polynomial groups
                                        ("CCS2", dict(n=9, l=2, Bgbit=8, parties=3)),          # l = 2: 4 groups per batch, two output tasks per wave
                                        ("CCS4", dict(n=6)),                                    # l = 4, 4 parties: one group per batch... (G = 2)
-                                       ("CCS2", dict(n=7, l=5, Bgbit=6, parties=1))])         # one group per batch, single party
+                                       ("CCS2", dict(n=7, l=5, Bgbit=6, parties=1)),          # one group per batch, single party
+                                       ("CCS8", dict(n=3))])                                   # the reference's 8-party set: 45 digit rows per stage
 def test_ccs_reduced_bit_exact(O, name, over):
     import thfhe
     p, s, K, orc, ck = make(O, name, **over)

@@ -54,6 +54,7 @@ PARAM_SETS = {
     # CCS scheme (mk_bootstrap / mk_gate_nand): mktfhe_parameters_2party / _4party, mk_api.jl:4-10,56-62
     "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
     "CCS4": dict(n=560, N=1024, k=1, l=4, Bgbit=8, ks_t=8, ks_basebit=2, torus_bits=32, parties=4),
+    "CCS8": dict(n=560, N=1024, k=1, l=5, Bgbit=6, ks_t=8, ks_basebit=2, torus_bits=32, parties=8),   # mktfhe_parameters_8party, mk_api.jl:111-117
 }
 
 
