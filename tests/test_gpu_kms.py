@@ -22,10 +22,11 @@ def setup(O, name, n, parties=None, seed=7):
     return p, K, orc, ck
 
 
-@pytest.mark.parametrize("name,n,parties", [("KMS2", 12, None), ("KMS2-fast", 5, None), ("KMS4", 6, None), ("KMS8", 4, 3)])
+@pytest.mark.parametrize("name,n,parties", [("KMS2", 12, None), ("KMS2-fast", 5, None), ("KMS4", 6, None), ("KMS8", 4, 3), ("KMS16", 3, 3), ("KMS32", 3, 2)])
 def test_kms_pieces_and_gates_bit_exact(O, name, n, parties):
     # KMS2: l_gsw = 3, Bgbit 13 -> two-part digits, 12 row parts (two LDS batches); KMS4: l_gsw = 5, Bgbit 8 -> 10 row parts;
-    # KMS8 gadgets (l_gsw = 4, Bgbit 11 -> 16 row parts, three batches; l_lev = 3; l_uni = 8) on three parties
+    # KMS8 gadgets (l_gsw = 4, Bgbit 11 -> 16 row parts, three batches; l_lev = 3; l_uni = 8) on three parties; KMS16 / KMS32 gadgets
+    # (gsw 5/9, lev 3/6, uni 9/4 and gsw 6/8, lev 3/7, uni 16/2: the 16- and 32-party sets, mk_api.jl:194-202, 225-233) on three / two parties
     from thfhe import kms
     p, K, orc, ck = setup(O, name, n, parties)
     a, b = np.array([0, 0, 1, 1, 1]), np.array([0, 1, 0, 1, 1])

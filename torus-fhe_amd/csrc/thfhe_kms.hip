@@ -332,13 +332,17 @@ int thfhe_kms_ctx_create(const thfhe_kms_params *p, const int64_t *gsw, const in
     if (!c) return thfhe_fail(THFHE_E_NOMEM, "out of host memory");
     c->p = *p;
     c->device = device;
-    c->parts = p->bg_gsw > 10 ? 2 : 1;          // digits beyond 10 bit are cut in two (FP64 exactness bound)
+    // exactness: RP * N * 2^(part width - 1) * 2^15 must stay below 2^37 (N = 2048 bound of DESIGN.md section 4.3).  Digits are cut in two
+    // balanced parts when they are wider than 10 bit OR when the whole-digit sum would leave the bound (many rows: the 16-party set's
+    // l = 5, Bgbit 9 gives 2^37.3)
+    const int N = 2048;
+    auto sum_bound = [&](int parts, int bits) { return (double)(2 * p->l_gsw * parts) * N * (double)(1 << (bits - 1)) * 32768.0; };
     c->lo_bits = (p->bg_gsw + 1) / 2;
+    c->parts = (p->bg_gsw > 10 || sum_bound(1, p->bg_gsw) > 137438953472.0) ? 2 : 1;
     c->row_words = 128 * ((p->n + 1 + 127) / 128);
-    const int RP = 2 * p->l_gsw * c->parts, N = 2048;
-    // exactness: RP * N * 2^(part width - 1) * 2^15 must stay below 2^37 (N = 2048 bound of DESIGN.md section 4.3)
+    const int RP = 2 * p->l_gsw * c->parts;
     const int part_bits = c->parts == 2 ? c->lo_bits : p->bg_gsw;
-    if ((double)RP * N * (double)(1 << (part_bits - 1)) * 32768.0 > 137438953472.0 /* 2^37 */) {
+    if (sum_bound(c->parts, part_bits) > 137438953472.0 /* 2^37 */) {
         delete c;
         return thfhe_fail(THFHE_E_UNSUPPORTED, "gsw gadget outside the FP64 exactness bound of the N = 2048 transform");
     }

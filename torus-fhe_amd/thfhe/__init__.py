@@ -73,6 +73,8 @@ KMS_PARAM_SETS = {
     "KMS2-fast": dict(n=560, N=2048, parties=2, l_gsw=3, bg_gsw=13, l_lev=2, bg_lev=7, l_uni=3, bg_uni=10, ks_t=8, ks_basebit=2),
     "KMS4": dict(n=560, N=2048, parties=4, l_gsw=5, bg_gsw=8, l_lev=2, bg_lev=8, l_uni=5, bg_uni=8, ks_t=8, ks_basebit=2),
     "KMS8": dict(n=560, N=2048, parties=8, l_gsw=4, bg_gsw=11, l_lev=3, bg_lev=6, l_uni=8, bg_uni=4, ks_t=8, ks_basebit=2),
+    "KMS16": dict(n=560, N=2048, parties=16, l_gsw=5, bg_gsw=9, l_lev=3, bg_lev=6, l_uni=9, bg_uni=4, ks_t=8, ks_basebit=2),    # mk_api.jl:194-202
+    "KMS32": dict(n=560, N=2048, parties=32, l_gsw=6, bg_gsw=8, l_lev=3, bg_lev=7, l_uni=16, bg_uni=2, ks_t=8, ks_basebit=2),   # mk_api.jl:225-233
 }
 
 
