@@ -85,9 +85,9 @@ def test_mk4_bit_exact(O):
     ck.close()
 
 
-@pytest.mark.parametrize("name,n", [("MK5", 520), ("MK8", 96)])
+@pytest.mark.parametrize("name,n", [("MK3", 510), ("MK5", 520), ("MK8", 96)])
 def test_mk5_mk8_bit_exact(O, name, n):
-    # mktfhe_parameters_5party_3gen (P = 5, l = 3, Bgbit = 6; full size) and mktfhe_parameters_8party_3gen (P = 8, l = 4, Bgbit = 4:
+    # mktfhe_parameters_3party_3gen (P = 3, l = 2, Bgbit = 7; full size, J/mk_api.jl:44-50), mktfhe_parameters_5party_3gen (P = 5, l = 3, Bgbit = 6; full size) and mktfhe_parameters_8party_3gen (P = 8, l = 4, Bgbit = 4:
     # eight digit rows, key rows streamed through a register window; LWE dimension reduced to keep the 8-party oracle in seconds)
     # J/mk_api.jl:98-104, 140-146.  Small batches take the one-gate-per-workgroup kernel, 300 gates the two-gate kernel (l <= 3).
     import thfhe
