@@ -79,6 +79,6 @@ if rank == 0:
     rot = s2.get("rotations", 0) + NTRAIN * (s1.get("rotations", 0) // max(len(st["my_rows"]), 1))
     print(json.dumps(dict(workload=f"KNN decision, {NTRAIN} train rows x {NCOL} columns x {NB} bit (reference circuit)", n_gpus=world,
                           blind_rotations=rot, seconds=dt, rotations_per_s=rot / dt,
-                          levels=dict(phase1=s1.get("levels"), phase2=s2.get("levels")), launches=dict(phase1=s1.get("launches"), phase2=s2.get("launches")),
+                          levels=dict(phase1=s1.get("levels"), phase2=s2.get("levels")), phase_seconds=dict(phase1=s1.get("seconds"), phase2=s2.get("seconds")), launches=dict(phase1=s1.get("launches"), phase2=s2.get("launches")),
                           distances=got_d, sorted_distances=got_sorted, count=got_count, decision=got_dec,
                           label_of_test_record=test[NCOL - 1], correct=bool(ok))), flush=True)

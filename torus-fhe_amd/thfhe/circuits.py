@@ -9,6 +9,8 @@ independent gates of a level -- and of independent sub-circuits placed in the sa
 Bit vectors are MSB-first lists of wire ids, as in the reference (index nbits-1 = least significant bit,
 src/bootstrap_modules.cpp:95).
 """
+import time
+
 import numpy as np
 
 from . import AND, COPY, MUX, NOT, OR, XOR
@@ -207,7 +209,9 @@ def knn_decision_sharded(ck, plan, test, train, threshold, all_zero, all_one, ls
     if mine:
         c1, dist, copies = plan.phase1(len(mine))
         in1 = np.concatenate([test.reshape(-1, words), train[mine].reshape(-1, words)] + consts + [zero])
+        _t = time.perf_counter()
         v1 = evaluate(ck, c1, in1, st1)
+        st1["seconds"] = st1.get("seconds", 0.0) + time.perf_counter() - _t
         for q, j in enumerate(mine):
             for col in range(ncol):
                 gathered[j, col] = v1[copies[q][col]]
@@ -220,7 +224,9 @@ def knn_decision_sharded(ck, plan, test, train, threshold, all_zero, all_one, ls
     thr = np.asarray(threshold, np.int32).reshape(nb, words)
     in2 = np.concatenate([gathered[:, :ncol].reshape(-1, words), gathered[:, ncol].reshape(-1, words), thr] + consts + [zero])
     st2 = {}
+    _t = time.perf_counter()
     v2 = evaluate(ck, c2, in2, st2)
+    st2["seconds"] = time.perf_counter() - _t
     if stats is not None:
         stats.update(phase1=st1, phase2=st2, my_rows=mine)
     return dict(decision=v2[decision], count=v2[count], sorted_dists=np.stack([v2[w] for w in sdists]), dists=gathered[:, ncol])
