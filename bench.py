@@ -239,13 +239,13 @@ def main():
                "note": "algorithmic bytes = SURVEY.md 8(d) per-gate figure x gates per launch; NOT a bound for these kernels (see hbm_measured_frac)"}
     roof = {"kernel": kernel, "avg_launch_ms": br_avg_ms, "keyswitch_avg_launch_ms": float(np.mean(ks_ms)),
             "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-            "hbm_measured_frac": None, "fp64_issue_frac": None, "lds_busy": None, "hbm_algorithmic": hbm_alg}
+            "hbm_measured_frac": None, "fp64_issue_frac": None, "lds_busy": None, "valu_busy": None, "hbm_algorithmic": hbm_alg}
     counters, why = load_counters(args.set, B, kernel)
     roof["counters_source"] = why
     if counters is not None:
         from summarize_profile import FP64_PEAK_GINST, FP64_PEAK_TFLOPS, derive
         d = derive(counters, br_s)   # counters of the same kernel sources and workload, combined with the launch time measured in THIS run
-        roof.update({k: d.get(k) for k in ("traffic", "hbm_measured_frac", "fp64_issue_frac", "lds_busy")})
+        roof.update({k: d.get(k) for k in ("traffic", "hbm_measured_frac", "fp64_issue_frac", "lds_busy", "valu_busy")})
         cand = {"fp64_valu_issue": d.get("fp64_issue_frac"), "lds": d.get("lds_busy"), "hbm": d.get("hbm_measured_frac")}
         cand = {k: v for k, v in cand.items() if v is not None}
         if cand:

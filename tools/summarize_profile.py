@@ -50,6 +50,10 @@ def derive(counters, launch_seconds):
     out["lds_busy"] = lds / (CUS * CLK_HZ * launch_seconds) if lds is not None else None   # LDS-array cycles, one array per CU
     valu = c.get("SQ_INSTS_VALU")
     out["valu_wave_insts_per_launch"] = valu
+    # all vector instructions, FP64 or not: SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave has a VALU instruction in flight,
+    # summed over the chip; divided by the SIMD-cycles of the launch it is the share of the time the vector pipes are occupied
+    act = c.get("SQ_ACTIVE_INST_VALU")
+    out["valu_busy"] = act * 4 / (CUS * SIMDS_PER_CU * CLK_HZ * launch_seconds) if act is not None else None
     busy = c.get("SQ_BUSY_CYCLES")
     out["effective_clock_ghz"] = busy / 32 / launch_seconds / 1e9 if busy is not None else None   # counter is summed over the 32 shader engines
     return out
