@@ -8,8 +8,16 @@ reference's fixtures and KNN application use), inputs and keys already resident 
 replicated keys (weak scaling, no data-path collective -- SURVEY.md section 8e); rank 0 prints ONE
 JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--set SK-128] [--batch 4096] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--set SK-128] [--batch 4096] [--mode replicated|party] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no launcher (WORLD_SIZE unset): this process starts the N ranks ITSELF, as child processes and before
+anything touches the GPU, relays rank 0's JSON line and exits non-zero if any rank does.  Under a launcher WORLD_SIZE must equal N.
+
+`--mode party` (BASELINE.json configs[4], "RCCL combine"; 3-gen sets only): the parties' keys are dealt over pipeline groups of
+min(N, P) GPUs (thfhe/party_sharded.py): the accumulator travels rank to rank (send/recv), the extracted sample is broadcast, the
+key-switched parts are all-gathered -- 3gen_mk_internals.jl:78-84 + mk_internals.jl:730-744.  Every group evaluates its own batch of
+`--batch` x group-size gates per step, so a GPU's share of CMuxes is the same at every N (weak scaling).
 """
 import argparse
 import json
@@ -37,12 +45,62 @@ def algorithmic_bytes(p, rotations=1):
     return dict(bk=bk, ksk=ksk, io=io, total=bk + ksk + io)
 
 
+def spawn_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one (which has not imported torch
+    or loaded the HIP library: a process that has initialised the GPU must never be replaced or forked into ranks), one per GPU, with
+    the torch.distributed environment, on a free port of 127.0.0.1.  Rank 0's stdout is relayed (the ONE JSON line), the other
+    ranks' stdout goes to stderr.  Returns the exit code: non-zero as soon as any rank fails (the rest are then terminated by PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), THFHE_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    pending = set(range(n_gpus))
+    out0 = b""
+    while pending:
+        for r in sorted(pending):
+            pr = procs[r]
+            try:
+                if r == 0:
+                    o, _ = pr.communicate(timeout=0.5)
+                    out0 += o or b""
+                else:
+                    pr.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            if pr.returncode != 0 and rc == 0:
+                rc = pr.returncode if pr.returncode > 0 else 1
+                print(f"[bench] rank {r} exited with code {pr.returncode}: stopping the other ranks", file=sys.stderr, flush=True)
+                for q in pending:
+                    procs[q].terminate()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
 def dist_setup(n_gpus):
-    """torch.distributed over RCCL ("nccl") when launched by torch.distributed.run; returns (rank, world, barrier, max_reduce, backend).
-    The backend is chosen ONCE from the environment (THFHE_BENCH_BACKEND, default nccl; "gloo" for CPU rehearsals) and a failure
-    of it is fatal on every rank -- a rank that quietly switched backends would leave the others hanging in the first collective."""
+    """torch.distributed over RCCL ("nccl"); returns (rank, world, barrier, max_reduce, backend).  The world comes from the launcher's
+    environment (torch.distributed.run, or spawn_ranks above) and MUST equal --gpus: a mismatch exits non-zero instead of measuring a
+    different job than the one asked for.  The backend is chosen ONCE from the environment (THFHE_BENCH_BACKEND, default nccl; "gloo"
+    for CPU rehearsals) and a failure of it is fatal on every rank -- a rank that quietly switched backends would leave the others
+    hanging in the first collective."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != n_gpus:
+        print(f"[bench] --gpus {n_gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {n_gpus}` (spawns its own ranks) or "
+              f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {n_gpus} --master-addr 127.0.0.1 bench.py --gpus {n_gpus}`",
+              file=sys.stderr, flush=True)
+        raise SystemExit(2)
     if world == 1:
         return 0, 1, (lambda: None), (lambda x: x), "none"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -91,15 +149,16 @@ def dist_setup(n_gpus):
     return rank, world, barrier, max_reduce, backend
 
 
-def cpu_baseline(K, p_name, xa, xb, gpu_out, per_thread):
+def cpu_baseline(K, p_name, mk, xa, xb, gpu_out, per_thread):
     """Time the CPU oracle (exact-integer restatement of the reference path, OpenMP over gates = the reference's only parallel
     pattern, src/KNN_medical_data.cpp:681) on the first gates of the same workload, on the CPUs this process may really use
-    (affinity mask capped by the cgroup quota); median of 3 runs; also cross-check the GPU output on the sample."""
+    (affinity mask capped by the cgroup quota); median of 3 runs; also cross-check the GPU output on the sample.
+    Single-key: J/bootstrap.jl + J/keyswitch.jl restated; 3-gen multi-key: J/3gen_mk_internals.jl:59-116 + J/mk_internals.jl:730-744."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     threads = O.usable_cpus()
     p = O.make_params(p_name)
-    orc = O.Oracle(p, K.bk, K.ksk)
+    orc = (O.MKOracle if mk else O.Oracle)(p, K.bk, K.ksk)
     L = O.lib()
     L.oracle_set_threads(threads)
     sample = min(per_thread * threads, xa.shape[0])
@@ -112,20 +171,20 @@ def cpu_baseline(K, p_name, xa, xb, gpu_out, per_thread):
     dt = sorted(runs)[1]
     exact = bool(np.array_equal(ref, gpu_out[:sample]))
     L.oracle_set_threads(1)
-    n1 = min(4, sample)
+    n1 = min(4 if not mk else 1, sample)
     one = []
-    for _ in range(3):
+    for _ in range(3 if not mk else 1):
         t0 = time.perf_counter()
         orc.gates(O.NAND, xa[:n1], xb[:n1])
         one.append((time.perf_counter() - t0) / n1)
     L.oracle_set_threads(threads)
-    single = 1.0 / sorted(one)[1]
+    single = 1.0 / sorted(one)[len(one) // 2]
     value = sample / dt
     return dict(value=value, unit="gates/s", cores=threads, threads=threads, kind="port",
                 per_thread_gates_per_s=value / threads, single_thread_value=single, scaling_efficiency=value / (threads * single),
                 affinity_cpus=len(os.sched_getaffinity(0)), runs_s=[round(r, 3) for r in runs],
                 sample=f"first {sample} NAND gates of the same batch ({per_thread} per thread), exact-integer oracle (64-bit NTT engine, per-thread "
-                       f"scratch, no allocation in the CMux loop; NOT libtfhe's AVX FFT), OpenMP schedule(dynamic) over gates on {threads} threads "
+                       f"scratch, no allocation in the CMux loop; NOT libtfhe's AVX FFT / Julia's FFT), OpenMP schedule(dynamic) over gates on {threads} threads "
                        f"(cgroup CPU quota; the affinity mask shows {len(os.sched_getaffinity(0))}), median of 3 runs = {dt:.2f} s",
                 gpu_bit_exact_on_sample=exact)
 
@@ -154,6 +213,113 @@ def load_counters(param_set, batch, kernel):
                   if stale else "no committed counter file for this workload")
 
 
+def make_keys(args, p, mk, device):
+    """Synthetic key material of SURVEY.md section 8(d): deterministic seed, the parameter set's own noise levels (thfhe.SIGMAS, KeyError
+    for a set without an entry).  The 16+-party sets generate their bootstrapping key on the device (section 13 of DESIGN.md)."""
+    import thfhe
+    from thfhe import keygen
+    sig = thfhe.SIGMAS[args.set]
+    if mk:
+        wide = p.Bgbit > 10
+        return keygen.MKSecretKeySet(p, seed=0x5EED0001, sigma_lwe=sig["lwe"], sigma_bk=sig["bk"], sigma_ks=sig["ks"], device=device if wide else None)
+    return keygen.SecretKeySet(p, seed=0x5EED0001, sigma_lwe=sig["lwe"], sigma_bk=sig["bk"], sigma_ks=sig["ks"])
+
+
+def dry_topology(args):
+    """--dry-topology: the rank start-up, rendezvous, barrier and max-over-ranks path of a real run without touching a GPU or the HIP
+    library (CPU rehearsal of `--gpus N`; tests/test_sharding_gloo.py)."""
+    rank, world, barrier, max_reduce, backend = dist_setup(args.gpus)
+    barrier()
+    slowest = max_reduce(1.0 + rank)
+    res = {"dry_topology": True, "n_gpus": world, "requested_gpus": args.gpus, "timing_backend": backend, "mode": args.mode,
+           "slowest_rank_time": slowest, "spawned_by_bench": os.environ.get("THFHE_BENCH_SPAWNED") == "1"}
+    if args.mode == "party":
+        sys.path.insert(0, os.path.join(ROOT, "torus-fhe_amd"))
+        import thfhe
+        from thfhe.party_sharded import party_topology
+        P = thfhe.make_params(args.set).parties
+        res["party_topology"] = [party_topology(world, P, r) for r in range(world)]
+    barrier()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+def run_party(args, p, rank, world, barrier, max_reduce, backend, device):
+    """--mode party: one step = every pipeline group evaluates `batch x group_size` NAND gates through PartyShardedEvaluator."""
+    import torch
+    import torch.distributed as dist
+    import thfhe
+    from thfhe.party_sharded import HipPartyBackend, PartyShardedEvaluator, party_topology
+    topo = party_topology(world, p.parties, rank)
+    group = None
+    if world > 1 and topo["groups"] > 1:   # every rank takes part in creating every group
+        for g in range(topo["groups"]):
+            ranks = list(range(g * topo["group_size"], (g + 1) * topo["group_size"]))
+            h = dist.new_group(ranks)
+            if g == topo["group"]:
+                group = h
+    K = make_keys(args, p, True, device)
+    first, last = topo["parties"]
+    be = HipPartyBackend(p, (first, last), K.bk[first:last], K.ksk[first:last], device=device)
+    ev = PartyShardedEvaluator(p, be, group=group, pipeline_chunks=args.pipeline_chunks)
+    B = args.batch * topo["group_size"]
+    gseed = 0x5EED0002 + 2 * topo["group"]      # every rank of a group sees the same ciphertexts (mk_internals.jl:23-37)
+    rng = np.random.default_rng(gseed)
+    bits_a, bits_b = rng.integers(0, 2, B), rng.integers(0, 2, B)
+    xa, xb = K.encrypt(bits_a, seed=gseed), K.encrypt(bits_b, seed=gseed + 1)
+    ta, tb = torch.from_numpy(xa).to(be.device), torch.from_numpy(xb).to(be.device)
+    be.timing = []
+    for _ in range(args.warmup):
+        out = ev.gates(thfhe.NAND, ta, tb)
+    torch.cuda.synchronize(be.device)
+    be.timing = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = ev.gates(thfhe.NAND, ta, tb)
+        torch.cuda.synchronize(be.device)
+    barrier()
+    elapsed = max_reduce(time.perf_counter() - t0)
+    rot_ms = [a.elapsed_time(b) for a, b in be.timing]
+    got = out.cpu().numpy()
+    errors = int((K.decrypt(got) != ~(bits_a.astype(bool) & bits_b.astype(bool))).sum())
+    if errors:
+        raise RuntimeError(f"rank {rank}: {errors} of {B} bootstrapped NAND outputs decrypt wrongly")
+    if rank != 0:
+        return None
+    value = topo["groups"] * B * args.steps / elapsed
+    launches_per_step = max(1, len(rot_ms) // max(1, args.steps))
+    jobs_per_launch = B / launches_per_step
+    ab = algorithmic_bytes(p)
+    per_rot = jobs_per_launch * (ab["bk"] * (last - first) // p.parties + 2 * 2 * p.N * 8)   # this rank's share of the key stream + accumulator in / out
+    avg_ms = float(np.mean(rot_ms)) if rot_ms else None
+    roof = {"kernel": ("mk_blind_rotate_coop2k_kernel" if p.N == 2048 else "mk_blind_rotate_coop_kernel") + f"<{p.l}>",
+            "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step, "gates_per_launch": jobs_per_launch,
+            "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+            "counters_source": "no PMC pass for the party-sharded piece launches (the kernel is the replicated mode's; see that mode's line)",
+            "hbm_algorithmic": {"bytes_per_launch": per_rot, "achieved_gbs": per_rot / (avg_ms * 1e-3) / 1e9 if avg_ms else None, "peak_gbs": HBM_PEAK_GBS,
+                                "frac": per_rot / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms else None,
+                                "note": "SURVEY.md 8(d) model (this rank's parties' key once per gate); not a bound for this kernel"}}
+    comm = {"accumulator_bytes_per_gate_per_hop": 2 * p.N * 8, "extracted_sample_bytes_per_gate": (p.N + 1) * 4,
+            "keyswitched_part_bytes_per_gate_per_rank": ((last - first) * p.n + 1) * 4, "hops": topo["group_size"] - 1,
+            "collectives": "send/recv (accumulator pipeline), broadcast (extracted LWE), all_gather (key-switched parts)" if topo["group_size"] > 1
+                           else "none (one rank holds every party: the same piece kernels, no transport)"}
+    return {
+        "metric": f"bootstrapped gates/sec (NAND, N={p.N})", "value": value, "unit": "gates/s",
+        "n_gpus": world, "requested_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{B} bootsNAND per pipeline group per step ({args.batch} x {topo['group_size']} ranks), 3-gen multi-key {args.set} "
+                               f"(P={p.parties}, n={p.n}, N={p.N}, k={p.k}, l={p.l}, Bgbit={p.Bgbit}, ks {p.ks_t}/{p.ks_basebit}), party-sharded keys, "
+                               "ciphertexts resident in HBM",
+                   "gates_per_group_per_step": B, "param_set": args.set,
+                   "parallelism": f"party pipeline: {topo['groups']} group(s) x {topo['group_size']} rank(s), {last - first} parties per rank, "
+                                  f"{args.pipeline_chunks} pipeline chunks, {'RCCL' if backend == 'nccl' else backend} combine",
+                   "mode": "party", "timing_backend": backend},
+        "roofline": roof, "party_comm": comm, "bit_exact_decrypt_errors": errors,
+    }, K, xa, xb, got
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,12 +327,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--set", default="SK-128")
     ap.add_argument("--batch", type=int, default=4096, help="gates per GPU per step")
+    ap.add_argument("--mode", choices=("replicated", "party"), default="replicated",
+                    help="replicated: every GPU holds all keys and runs its own batch; party: the parties' keys are dealt over the GPUs (3-gen sets)")
+    ap.add_argument("--pipeline-chunks", type=int, default=4, help="--mode party: slices of the batch in flight along the party pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-per-thread", type=int, default=8, help="gates per host thread in the CPU baseline sample")
+    ap.add_argument("--cpu-per-thread", type=int, default=None, help="gates per host thread in the CPU baseline sample (default 8; 1 for multi-key sets)")
+    ap.add_argument("--dry-topology", action="store_true", help="rank start-up + rendezvous + barrier only (no GPU): rehearsal of --gpus N")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("[bench] --gpus must be >= 1")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))   # nothing above has touched torch, HIP or the GPU
+    if args.dry_topology:
+        return dry_topology(args)
+
+    if args.mode == "party":
+        os.environ["THFHE_TORCH_FIRST"] = "1"   # torch before libthfhe_hip.so: the piece API works on torch tensors
     import thfhe
-    from thfhe import keygen
 
     rank, world, barrier, max_reduce, backend = dist_setup(args.gpus)
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -177,16 +355,23 @@ def main():
 
     p = thfhe.make_params(args.set)
     mk = p.torus_bits == 64
-    if mk:   # 3-gen multi-key (BASELINE.json configs[2], [4]); noise per J/mk_api.jl:32-38,84-90
-        lwe_sigma = {"MK2": 2.0**-13.52, "MK3": 2.0**-13.26, "MK4": 2.0**-13.26, "MK4-N2048": 2.0**-13.26, "MK16": 2.0**-15.34, "MK32": 2.0**-16.12,
-                     "MK64": 2.0**-16.90, "MK128": 2.0**-17.42}.get(args.set, 2.0**-13.52)
-        wide = p.Bgbit > 10   # the 16+-party sets (J/mk_api.jl:214-298): one level, 24 .. 26-bit base, RLWE noise 2^-62; keys generated on the device
-        K = keygen.MKSecretKeySet(p, seed=0x5EED0001, sigma_lwe=lwe_sigma, sigma_bk=2.0**-62 if wide else 2.0**-30.70, device=device if wide else None)
-        ck = thfhe.MKCloudKey(p, K.bk, K.ksk, device=device)
-    else:    # SURVEY.md section 8(d) synthetic-input recipe
-        sig = dict(lwe=2.0**-15, bk=2.0**-25, ks=2.0**-15)
-        K = keygen.SecretKeySet(p, seed=0x5EED0001, sigma_lwe=sig["lwe"], sigma_bk=sig["bk"], sigma_ks=sig["ks"])
-        ck = thfhe.CloudKey(p, K.bk, K.ksk, device=device)
+    per_thread = args.cpu_per_thread if args.cpu_per_thread is not None else (1 if mk else 8)
+    cpu_ok = world == 1 and not args.no_cpu_baseline and p.parties * p.n * (p.N // 1024) <= 4500   # bounded sample: <= ~30 s of host work
+
+    if args.mode == "party":
+        if not mk:
+            raise SystemExit("[bench] --mode party needs a 3-gen multi-key set (MK2, MK4, MK4-N2048, ...)")
+        r = run_party(args, p, rank, world, barrier, max_reduce, backend, device)
+        if rank != 0:
+            return
+        res, K, xa, xb, got = r
+        if cpu_ok:
+            res["cpu_baseline"] = cpu_baseline(K, args.set, True, xa, xb, got, per_thread)
+        print(json.dumps(res), flush=True)
+        return
+
+    K = make_keys(args, p, mk, device)
+    ck = (thfhe.MKCloudKey if mk else thfhe.CloudKey)(p, K.bk, K.ksk, device=device)
     words = p.parties * p.n + 1
 
     B = args.batch
@@ -227,9 +412,7 @@ def main():
     br_avg_ms = float(np.mean(br_ms))
     br_s = br_avg_ms * 1e-3
     br_bytes = B * (ab["bk"] + 2 * words * 4 + (p.N + 1) * 4)  # blind-rotate launch: key stream + records in, extracted out
-    kernel = ((("mk_blind_rotate_coop2k_kernel" if p.N == 2048 else
-                ("mk_blind_rotate_pair_kernel" if (p.l <= 3 and B > 256) else "mk_blind_rotate_coop_kernel")) + f"<{p.l}>") if mk
-              else (f"sk_blind_rotate_ring_kernel<{p.l}>" if B > 1024 else f"sk_blind_rotate_coop_kernel<{p.l}>"))
+    kernel = ck.rotation_kernel_name(B)
     # SURVEY.md 8(d)'s HBM model, kept under its own name: it charges every gate a private pass over the transformed key, while the kernels
     # share each key chunk between the gates of a workgroup and all workgroups hit L2 / Infinity Cache -- it can exceed 1 and bounds nothing
     hbm_alg = {"bytes_per_launch": br_bytes, "achieved_gbs": br_bytes / br_s / 1e9, "peak_gbs": HBM_PEAK_GBS,
@@ -262,19 +445,22 @@ def main():
             roof.update(achieved=d["traffic"] / br_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=d["hbm_measured_frac"])
         roof["effective_clock_ghz_at_profile"] = d.get("effective_clock_ghz")
     res = {
-        "metric": "bootstrapped gates/sec (NAND, N=1024)", "value": value, "unit": "gates/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": f"bootstrapped gates/sec (NAND, N={p.N})", "value": value, "unit": "gates/s",
+        "n_gpus": world, "requested_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{B} independent bootsNAND per GPU, {'3-gen multi-key' if mk else 'single-key'} {args.set} "
                                f"(P={p.parties}, n={p.n}, N={p.N}, k={p.k}, l={p.l}, Bgbit={p.Bgbit}, ks {p.ks_t}/{p.ks_basebit}), keys+ciphertexts resident in HBM",
                    "gates_per_gpu_per_step": B, "param_set": args.set, "parallelism": f"gate-batch sharding x{world}, replicated keys",
-                   "timing_backend": backend},
+                   "mode": "replicated", "timing_backend": backend},
         "roofline": roof,
         "bit_exact_decrypt_errors": errors,
     }
-    if world == 1 and not args.no_cpu_baseline and not mk:
-        res["cpu_baseline"] = cpu_baseline(K, args.set, xa, xb, out, args.cpu_per_thread)
+    if cpu_ok:
+        res["cpu_baseline"] = cpu_baseline(K, args.set, mk, xa, xb, out, per_thread)
+    elif world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = None
+        res["cpu_baseline_note"] = "skipped: one gate of this set is minutes of work for the exact CPU oracle (P x n CMuxes on the N = 2048 ring)"
     print(json.dumps(res), flush=True)
 
 

@@ -134,16 +134,17 @@ int thfhe_mk_set_pair_threshold(thfhe_mk_ctx *ctx, long max_single_jobs);
  * circuits mk_add_3gen ... mk_int_mul_3gen (J/3gen_mk_gates.jl:183-362).  Opcodes: NAND / OR / AND / XOR, AND3, MUX, NOT, COPY. */
 int thfhe_mk_dag_run(thfhe_mk_ctx *ctx, int32_t *wires, size_t n_inputs, const int32_t *gates, size_t n_gates, int64_t *stats);
 int thfhe_mk_bootstrap(thfhe_mk_ctx *ctx, int64_t mu, const int32_t *x, int32_t *out, size_t count);
-/* Party-sharded building blocks (optional mode: one rank per party holds only that party's keys, i.e. a
- * context created with parties = 1 from party p's key part).  All pointers are DEVICE pointers; calls enqueue on the context's
- * stream.  The accumulator travels between ranks as int64[count][2][N] (mask polynomial, body polynomial).
+/* Party-sharded building blocks (optional mode: a rank holds only the keys of a contiguous block of m
+ * parties, i.e. a context created with parties = m from those parties' key parts; m = 1 is one rank per party).  Below
+ * nb = m * n (the block's mask words) and P = the key set's total party count.  All pointers are DEVICE pointers; calls enqueue
+ * on the context's stream.  The accumulator travels between ranks as int64[count][2][N] (mask polynomial, body polynomial).
  *   prologue       : the gate's linear part (J/3gen_mk_gates.jl; op = -1: identity, i.e. plain mk_bootstrap_3gen of in0; which = 0 / 1
- *                    selects the first / second AND of the 3-gen MUX) + mod-switch (J/numeric-functions.jl:70-73) of this party's n
- *                    mask words [first_word, first_word + n) of records with rec_words = P_total*n + 1 words, and of b.
- *   rotate_partial : run this context's n CMuxes (J/3gen_mk_internals.jl:66-74) on every accumulator.  d_bara = int32[count][n]
- *                    mod-switched mask words of this party; d_acc_in == NULL starts from X^{-barb} * mu (first party).
+ *                    selects the first / second AND of the 3-gen MUX) + mod-switch (J/numeric-functions.jl:70-73) of this block's nb
+ *                    mask words [first_word, first_word + nb) of records with rec_words = P*n + 1 words, and of b.
+ *   rotate_partial : run this context's nb CMuxes (J/3gen_mk_internals.jl:66-84, party-major) on every accumulator.  d_bara =
+ *                    int32[count][nb] mod-switched mask words of this block; d_acc_in == NULL starts from X^{-barb} * mu (first block).
  *   extract        : rlwe_extract_sample_64 (J/rlwe.jl:70-74) -> int32[count][N+1]
- *   keyswitch      : keyswitch of the extracted samples with this context's key(s) -> int32[count][P*n+1]      */
+ *   keyswitch      : keyswitch of the extracted samples with this context's key(s) -> int32[count][nb+1]      */
 int thfhe_mk_prologue_dev(thfhe_mk_ctx *ctx, int op, int which, const int32_t *d_in0, const int32_t *d_in1, const int32_t *d_in2,
                           int rec_words, int first_word, int32_t *d_bara, int32_t *d_barb, size_t count);
 int thfhe_mk_rotate_partial_dev(thfhe_mk_ctx *ctx, const int32_t *d_bara, const int32_t *d_barb, int64_t mu,

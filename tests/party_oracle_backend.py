@@ -13,12 +13,16 @@ LIN = {O.NAND: (E8, -1, -1, 0), O.OR: (E8, 1, 1, 0), O.AND: (-E8, 1, 1, 0), O.XO
 
 class OraclePartyBackend:
     def __init__(self, params, party, bk_part, ksk_part):
-        self.params, self.party = params, party
+        """party: an index (key parts without a party axis) or a range (first, last+1) with key parts [parties of the range]..."""
+        if isinstance(party, int):
+            party, bk_part, ksk_part = (party, party + 1), np.asarray(bk_part)[None], np.asarray(ksk_part)[None]
+        self.params, self.first, self.count = params, party[0], party[1] - party[0]
+        self.party = self.first
         self.device = torch.device("cpu")
         d = params.as_dict()
-        d["parties"] = 1
+        d["parties"] = self.count
         self.p1 = O.make_params(**d)
-        self.orc = O.MKOracle(self.p1, np.asarray(bk_part)[None], np.asarray(ksk_part)[None])
+        self.orc = O.MKOracle(self.p1, np.asarray(bk_part), np.asarray(ksk_part))
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype)
@@ -34,7 +38,7 @@ class OraclePartyBackend:
         v[:, -1] += cb
         v = v.astype(np.uint32).view(np.int32)
         ms = np.vectorize(lambda w: O.lib().oracle_modswitch(int(w), p.N), otypes=[np.int32])
-        return (torch.from_numpy(ms(v[:, self.party * p.n:(self.party + 1) * p.n])), torch.from_numpy(ms(v[:, -1])))
+        return (torch.from_numpy(ms(v[:, self.first * p.n:(self.first + self.count) * p.n])), torch.from_numpy(ms(v[:, -1])))
 
     def rotate(self, bara, barb, mu, acc_in):
         p = self.params
@@ -46,10 +50,11 @@ class OraclePartyBackend:
                 O.lib().oracle_mul_by_monomial64(O.p64(tv), -int(barb[g]), p.N, O.p64(acc[1]))
             else:
                 acc = acc_in[g].numpy().copy()
-            for i in range(p.n):
-                a = int(bara[g, i])
-                if a != 0:
-                    acc = self.orc.mux_rotate(0, i, a, acc)
+            for q in range(self.count):      # party-major, 3gen_mk_internals.jl:78-84
+                for i in range(p.n):
+                    a = int(bara[g, q * p.n + i])
+                    if a != 0:
+                        acc = self.orc.mux_rotate(q, i, a, acc)
             out[g] = acc.reshape(2, p.N)
         return torch.from_numpy(out)
 

@@ -75,3 +75,47 @@ def test_kms2_truth_table_larger_n(O):
     assert np.abs(np.abs(K.phase(out).astype(np.float64) / 2.0**32) - 0.125).max() < 0.06
     assert np.array_equal(out[:2], orc.gates(O.NAND, ca[:2], cb[:2]))
     ck.close()
+
+
+@pytest.mark.parametrize("name,n,parties", [("KMS16", 2, 16), ("KMS32", 2, 32)])
+def test_kms_16_and_32_party_sets_at_the_real_party_count(O, name, n, parties):
+    # mktfhe_parameters_16party_new / _32party_new (mk_api.jl:194-202, 225-233) with ALL 16 / 32 parties (17 / 33 accumulator polynomials, the
+    # relinearisation index tables at their real width); only the LWE dimension is reduced.  Gate, fast_boot gate and the pre-key-switch sample.
+    from thfhe import kms
+    p, K, orc, ck = setup(O, name, n, parties, seed=11)
+    a, b = np.array([0, 1, 1]), np.array([1, 1, 0])
+    ca, cb = K.encrypt(a, 41), K.encrypt(b, 42)
+    out = kms.mk_gate_nand_new(ck, ca, cb)
+    assert np.array_equal(out, orc.gates(O.NAND, ca, cb)), name
+    assert np.array_equal(K.decrypt(out), ~(a.astype(bool) & b.astype(bool)))
+    u = ck.bootstrap_wo_keyswitch(ca[:1])
+    assert np.array_equal(u[0], orc.bootstrap_wo_keyswitch(ca[0]))
+    fast = kms.mk_gate_nand_new(ck, ca[:2], cb[:2], fast_boot=True)
+    assert np.array_equal(fast, orc.gates(O.NAND, ca[:2], cb[:2], fast_boot=True))
+    ck.close()
+
+
+def test_kms4_moderate_size_buffers_regrow_between_routes(O):
+    # KMS4 with all four parties, n = 32, 40 gates: the G-dependent index tables of the relinearisation (terms / first / pos behind the index
+    # list, W_EF / W_INDEX regrowing between parties and between the fast_boot and the normal route) at a batch where offsets matter.
+    # One context: fast_boot = True first, then False, then a LARGER batch again; sampled gates and pre-key-switch samples word for word.
+    from thfhe import kms
+    p, K, orc, ck = setup(O, "KMS4", 32, seed=13)
+    rng = np.random.default_rng(17)
+    G = 40
+    a, b = rng.integers(0, 2, G), rng.integers(0, 2, G)
+    ca, cb = K.encrypt(a, 51), K.encrypt(b, 52)
+    idx = np.array([0, 7, 19, 26, 39])
+    fast = kms.mk_gate_nand_new(ck, ca[:12], cb[:12], fast_boot=True)          # small batch through the fast route first
+    assert np.array_equal(fast[[0, 7, 11]], orc.gates(O.NAND, ca[[0, 7, 11]], cb[[0, 7, 11]], fast_boot=True))
+    out = kms.mk_gate_nand_new(ck, ca, cb)                                      # buffers regrow: 12 -> 40 gates, other route
+    assert np.array_equal(out[idx], orc.gates(O.NAND, ca[idx], cb[idx]))
+    assert np.array_equal(K.decrypt(out), ~(a.astype(bool) & b.astype(bool)))
+    fast = kms.mk_gate_nand_new(ck, ca, cb, fast_boot=True)                     # and back, at the full batch
+    assert np.array_equal(fast[idx], orc.gates(O.NAND, ca[idx], cb[idx], fast_boot=True))
+    assert np.array_equal(K.decrypt(fast), ~(a.astype(bool) & b.astype(bool)))
+    u = ck.bootstrap_wo_keyswitch(ca)
+    for g in (3, 38):
+        assert np.array_equal(u[g], orc.bootstrap_wo_keyswitch(ca[g])), g
+    assert np.array_equal(ck.gates(O.XOR, ca[:9], cb[:9])[[2, 8]], orc.gates(O.XOR, ca[[2, 8]], cb[[2, 8]]))   # shrinks again
+    ck.close()

@@ -156,6 +156,45 @@ def test_mk_wide_base_16_plus_party_sets_bit_exact(O, name, n, parties):
     ck.close()
 
 
+def test_mk16_full_size_bit_exact(O):
+    # mktfhe_parameters_16party_3gen AS WRITTEN (J/mk_api.jl:214-220): P = 16, n = 590, N = 2048, l = 1, Bgbit = 26, ks 4/3 -- 9 440 sequential
+    # CMuxes per gate through the three-part digit split and the shifted key-row copies of mk_expand_parts_kernel at the REAL party count
+    # (the reduced gadgets above stop at P = 3).  Four gates, every output word against the oracle.
+    import thfhe
+    p = O.make_params("MK16")
+    s = O.SIGMAS["MK16"]
+    K = O.MKKeys(p, 85, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    ck = thfhe.MKCloudKey(thfhe.make_params("MK16"), K.bk, K.ksk, device=0)
+    a = np.array([0, 1, 1, 0]); b = np.array([1, 1, 0, 0])
+    ca, cb = K.encrypt_bits(a, s["lwe"], 1), K.encrypt_bits(b, s["lwe"], 2)
+    got = ck.gates(thfhe.NAND, ca, cb)
+    assert np.array_equal(got, orc.gates(O.NAND, ca, cb))
+    assert np.array_equal(K.decrypt_bits(got), ~(a.astype(bool) & b.astype(bool)))
+    ck.close()
+
+
+def test_mk4_full_n_pair_kernel_32_gates_bit_exact(O):
+    # the l = 3 two-gates-per-workgroup kernel (the one bench.py --set MK4 measures) at the reference's full 4-party size, forced for a
+    # 33-gate batch (odd: a lone last gate): every output word of every gate against the oracle
+    import thfhe
+    p = O.make_params("MK4")
+    s = O.SIGMAS["MK4"]
+    K = O.MKKeys(p, 77, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    ck = thfhe.MKCloudKey(thfhe.make_params("MK4"), K.bk, K.ksk, device=0)
+    ck.set_pair_threshold(0)
+    rng = np.random.default_rng(21)
+    B = 33
+    a, b = rng.integers(0, 2, B), rng.integers(0, 2, B)
+    ca, cb = K.encrypt_bits(a, s["lwe"], 31), K.encrypt_bits(b, s["lwe"], 32)
+    got = ck.gates(thfhe.NAND, ca, cb)
+    assert ck.rotation_kernel_name(B) == "mk_blind_rotate_pair_kernel<3>"
+    assert np.array_equal(got, orc.gates(O.NAND, ca, cb))
+    assert np.array_equal(K.decrypt_bits(got), ~(a.astype(bool) & b.astype(bool)))
+    ck.close()
+
+
 def test_mk4_n2048_full_size(O):
     # BASELINE configs[4]: 4 parties, N = 2048, l = 3 at the reference's 4-party LWE dimension (n = 510)
     import thfhe

@@ -98,6 +98,68 @@ def test_concurrent_boots_calls_are_batched_and_correct(O):
     L.thfhe_tfhe_forget_key(ck)
 
 
+def test_key_swap_at_one_address_under_concurrent_callers(O):
+    """A libtfhe client may delete a key set and load another one at the SAME address.  One CloudKeySet struct is overwritten in place
+    (A -> B -> A) while eight threads call bootsNAND / bootsXOR through it and a straggler's 96-gate batch call on the previous key is
+    still in flight; every result must equal the batch API (thfhe.CloudKey on the same device) under the key the call was issued
+    against.  CPU twin of the lifetime logic under ThreadSanitizer: tests/test_keyslot.py."""
+    import threading
+    import time
+    import thfhe
+    import tfhe_structs as T
+    L = thfhe.lib()
+    for nm in ("bootsNAND", "bootsXOR", "thfhe_tfhe_forget_key"):
+        getattr(L, nm).restype = None
+    p = O.make_params("SK-128", n=40)
+    tp = thfhe.make_params(**p.as_dict())
+    keys = [O.SKKeys(p, 71 + q, 2.0**-25, 2.0**-15) for q in range(2)]
+    imgs = [T.TfheKeyImage(p, K.bk, K.ksk) for K in keys]
+    cks = [thfhe.CloudKey(tp, K.bk, K.ksk, device=0) for K in keys]
+    slot = T.CloudKeySet()                       # THE address every call goes through
+    ck = C.byref(slot)
+    SZ = C.sizeof(T.LweSample)
+    G = 32
+    rng = np.random.default_rng(5)
+    for phase, which in enumerate((0, 1, 0)):
+        K = keys[which]
+        a, b = rng.integers(0, 2, G), rng.integers(0, 2, G)
+        ca, cb = K.encrypt_bits(a, 2.0**-15, 300 + phase), K.encrypt_bits(b, 2.0**-15, 400 + phase)
+        # straggler: a batch call issued against the key that lives at the address NOW, still running when the address is overwritten
+        prev = keys[1 - which] if phase else None
+        if prev is not None:
+            pa = prev.encrypt_bits(rng.integers(0, 2, 96), 2.0**-15, 500 + phase)
+            spa, sba = T.make_samples(pa); spr, sbr = T.make_samples(np.zeros_like(pa))
+            strag = threading.Thread(target=lambda: L.thfhe_tfhe_gate_batch(O.NAND, spr, spa, spa, None, 96, ck))
+            strag.start()
+            time.sleep(0.002)
+        C.memmove(C.addressof(slot), C.addressof(imgs[which].cloud), C.sizeof(T.CloudKeySet))   # "delete + load at the same address"
+        sa, ba = T.make_samples(ca); sb, bb = T.make_samples(cb); sr, br = T.make_samples(np.zeros_like(ca))
+
+        def worker(tid):
+            for g in range(tid, G, 8):
+                f = L.bootsNAND if g % 2 == 0 else L.bootsXOR
+                f(C.byref(sr, g * SZ), C.byref(sa, g * SZ), C.byref(sb, g * SZ), ck)
+
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        got = T.read_samples(sr, br)
+        even, odd = np.arange(0, G, 2), np.arange(1, G, 2)
+        assert np.array_equal(got[even], cks[which].gates(O.NAND, ca[even], cb[even])), f"phase {phase}"
+        assert np.array_equal(got[odd], cks[which].gates(O.XOR, ca[odd], cb[odd])), f"phase {phase}"
+        assert np.array_equal(K.decrypt_bits(got[even]), ~(a[even].astype(bool) & b[even].astype(bool)))
+        if prev is not None:
+            strag.join()
+            # the straggler read the address either before or after the overwrite; its result must be a correct NAND under one of the two keys
+            res = T.read_samples(spr, sbr)
+            ok_prev = np.array_equal(res, cks[1 - which].gates(O.NAND, pa, pa))
+            ok_new = np.array_equal(res, cks[which].gates(O.NAND, pa, pa))
+            assert ok_prev or ok_new, f"phase {phase}: straggler batch matches neither key"
+    L.thfhe_tfhe_forget_key(ck)
+    for c in cks:
+        c.close()
+
+
 def test_cpp_client_links_and_matches_oracle(O, tmp_path):
     """tests/cpp/evaluate_demo.cpp: a plain g++ program written like the reference's C++ callers (Evaluate of src/Convert.cpp:28-33 from
     OpenMP threads, FullAdder of src/KNN_medical_data.cpp:134-157 with in-place carries), built against include/tfhe_shim.h and LINKED

@@ -30,7 +30,7 @@ RANK_SCRIPT = """
     import torch, torch.distributed as dist
     import oracle_lib as O
     import thfhe
-    from thfhe.party_sharded import PartyShardedEvaluator
+    from thfhe.party_sharded import PartyShardedEvaluator, party_topology
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     rank = dist.get_rank()
     mode = {mode!r}
@@ -38,13 +38,14 @@ RANK_SCRIPT = """
     s = O.SIGMAS[{pset!r}]
     K = O.MKKeys(p, 0x5EED0001, s["bk"], s["ks"])
     tp = thfhe.make_params(**p.as_dict())
+    first, last = party_topology(dist.get_world_size(), p.parties, rank)["parties"]   # this rank's block of parties
     if mode == "oracle":
         from party_oracle_backend import OraclePartyBackend
-        be = OraclePartyBackend(p, rank, K.bk[rank], K.ksk[rank])
+        be = OraclePartyBackend(p, (first, last), K.bk[first:last], K.ksk[first:last])
         dev = "cpu"
     else:
         from thfhe.party_sharded import HipPartyBackend
-        be = HipPartyBackend(tp, rank, K.bk[rank], K.ksk[rank], device=0)
+        be = HipPartyBackend(tp, (first, last), K.bk[first:last], K.ksk[first:last], device=0)
         dev = "cuda:0"
     ev = PartyShardedEvaluator(tp, be, pipeline_chunks={chunks})
     G = {gates}
@@ -105,6 +106,28 @@ def test_party_pipeline_four_gloo_ranks_mk4_shape_vs_oracle(tmp_path):
     assert sorted(o["rank"] for o in outs) == [0, 1, 2, 3]
     for o in outs:
         assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt")), o
+
+
+def test_party_blocks_two_gloo_ranks_hold_two_parties_each(tmp_path):
+    # bench.py --mode party at 2 GPUs with the 4-party set: rank r holds parties 2r, 2r+1 (party_topology), ONE accumulator hand-off
+    outs = run_two_ranks(tmp_path, "oracle", dict(n=6), gates=3, chunks=2, timeout=900, pset="MK4", world=2)
+    for o in outs:
+        assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt")), o
+
+
+def test_party_topology():
+    sys.path.insert(0, os.path.join(ROOT, "torus-fhe_amd"))
+    from thfhe.party_sharded import party_topology
+    assert party_topology(1, 4)["parties"] == (0, 4) and party_topology(1, 4)["groups"] == 1
+    assert [party_topology(2, 4, r)["parties"] for r in range(2)] == [(0, 2), (2, 4)]
+    assert [party_topology(4, 4, r)["parties"] for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    t = [party_topology(8, 4, r) for r in range(8)]     # BASELINE configs[4] at 8 GPUs: two pipelines of four ranks
+    assert all(x["groups"] == 2 and x["group_size"] == 4 for x in t)
+    assert [x["group"] for x in t] == [0, 0, 0, 0, 1, 1, 1, 1] and t[5]["group_ranks"] == [4, 5, 6, 7] and t[6]["parties"] == (2, 3)
+    with pytest.raises(ValueError):
+        party_topology(3, 4)
+    with pytest.raises(ValueError):
+        party_topology(6, 4)
 
 
 @pytest.mark.gpu

@@ -23,7 +23,7 @@ def test_two_rank_gloo_barrier_and_max_reduce(tmp_path):
         sys.path.insert(0, {ROOT!r})
         os.environ["THFHE_BENCH_BACKEND"] = "gloo"
         import bench
-        rank, world, barrier, max_reduce, backend = bench.dist_setup(2)
+        rank, world, barrier, max_reduce, backend = bench.dist_setup(2)   # --gpus 2 == WORLD_SIZE
         barrier()
         t = max_reduce(1.0 + rank)          # slowest rank defines the step time
         import numpy as np
@@ -45,6 +45,51 @@ def test_two_rank_gloo_barrier_and_max_reduce(tmp_path):
     assert sorted(o["rank"] for o in outs) == [0, 1]
     assert all(o["world"] == 2 and o["backend"] == "gloo" and o["t"] == 2.0 for o in outs)
     assert outs[0]["first"] != outs[1]["first"]
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env.update(extra)
+    return env
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    # `python bench.py --gpus 2` with NO launcher and NO environment prepared by the caller: bench.py itself starts two ranks (children, before
+    # anything touches a GPU), they rendezvous, and rank 0's single JSON line reports the world that really ran
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-topology"], env=_clean_env(THFHE_BENCH_BACKEND="gloo"),
+                        capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["requested_gpus"] == 2 and res["spawned_by_bench"] and res["timing_backend"] == "gloo"
+    assert res["slowest_rank_time"] == 2.0
+
+
+def test_bench_party_mode_topology_over_spawned_ranks():
+    # BASELINE.json configs[4] on 2 ranks: the 4-party set's keys in two blocks of two parties, one pipeline group
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-topology", "--mode", "party", "--set", "MK4-N2048"],
+                        env=_clean_env(THFHE_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    res = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 2 and [t["parties"] for t in res["party_topology"]] == [[0, 2], [2, 4]]
+    assert all(t["groups"] == 1 and t["group_size"] == 2 for t in res["party_topology"])
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    # under a launcher (WORLD_SIZE set) a mismatch with --gpus is an error, not a silently different job
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-topology"],
+                        env=_clean_env(THFHE_BENCH_BACKEND="gloo", WORLD_SIZE="2", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port())),
+                        capture_output=True, text=True, timeout=120)
+    assert pr.returncode != 0 and "WORLD_SIZE=2" in pr.stderr
+
+
+def test_bench_spawn_propagates_a_failing_rank():
+    # an unknown parameter set makes every rank fail before the rendezvous: the parent must exit non-zero and print no JSON line
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-topology", "--mode", "party", "--set", "NO-SUCH-SET"],
+                        env=_clean_env(THFHE_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+    assert pr.returncode != 0
+    assert not [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_algorithmic_bytes_match_baseline_md():

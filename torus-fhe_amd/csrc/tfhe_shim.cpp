@@ -4,12 +4,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstddef>
-#include <condition_variable>
-#include <map>
-#include <mutex>
 #include <vector>
 
 #include "../../include/thfhe_hip.h"
+#include "thfhe_keyslot.h"
 
 static_assert(sizeof(LweParams) == 24 && offsetof(LweParams, alpha_min) == 8, "LweParams layout");
 static_assert(sizeof(LweSample) == 24 && offsetof(LweSample, b) == 8 && offsetof(LweSample, current_variance) == 16, "LweSample layout");
@@ -28,7 +26,7 @@ namespace {
 
 // The device context is cached per key-set ADDRESS.  A libtfhe client may delete a key set and load another one at the same
 // address, so every entry carries a cheap fingerprint of the key it was built from (table pointers, shape, a few key words);
-// a mismatch rebuilds the device tables instead of evaluating under a stale key.
+// a mismatch builds new device tables instead of evaluating under a stale key (the old context dies with its last caller).
 struct Fingerprint {
     const void *bk_rows, *ks_rows;
     int32_t n, N, l, Bgbit, ks_t, ks_basebit;
@@ -58,13 +56,17 @@ Fingerprint fingerprint(const TFheGateBootstrappingCloudKeySet *bk) {
     }
     return f;
 }
-struct Entry {
-    thfhe_ctx *ctx;
-    int n;
-    Fingerprint fp;
+struct Request {
+    int op;
+    LweSample *result;
+    const LweSample *a, *b, *c;
+    bool done = false;
 };
-std::mutex g_mu;
-std::map<const TFheGateBootstrappingCloudKeySet *, Entry> g_ctx;
+// One Slot = device context + combining queue of one key set, held by shared_ptr for the whole of every call (thfhe_keyslot.h):
+// a key swap at the same address or thfhe_tfhe_forget_key can never destroy a context, mutex or condition variable under a caller.
+using Cache = thfhe_slot::Cache<thfhe_ctx, Fingerprint, Request>;
+using Entry = Cache::SlotT;
+Cache g_cache;
 
 [[noreturn]] void die(const char *what) {
     // the libtfhe gate functions return void and abort on internal errors ("Errors")
@@ -72,15 +74,7 @@ std::map<const TFheGateBootstrappingCloudKeySet *, Entry> g_ctx;
     std::abort();
 }
 
-Entry get_ctx(const TFheGateBootstrappingCloudKeySet *bk) {
-    std::lock_guard<std::mutex> g(g_mu);
-    const Fingerprint fp = fingerprint(bk);
-    auto it = g_ctx.find(bk);
-    if (it != g_ctx.end()) {
-        if (it->second.fp == fp) return it->second;
-        thfhe_ctx_destroy(it->second.ctx);  // another key set now lives at this address (serialises behind running calls: ctx mutex)
-        g_ctx.erase(it);
-    }
+bool build_ctx(const TFheGateBootstrappingCloudKeySet *bk, Entry &e) {
     const LweBootstrappingKey *b = bk->bk;
     thfhe_params p{};
     p.n = b->in_out_params->n;
@@ -111,11 +105,16 @@ Entry get_ctx(const TFheGateBootstrappingCloudKeySet *bk) {
                 for (int q = 0; q < p.n; q++) dst[q] = s->a[q];
                 dst[p.n] = s->b;
             }
-    Entry e{nullptr, p.n, fp};
+    e.n = p.n;
+    e.destroy = thfhe_ctx_destroy;
     const char *dev = std::getenv("THFHE_DEVICE");
-    if (thfhe_ctx_create(&p, bkc.data(), ksk.data(), dev ? std::atoi(dev) : 0, &e.ctx) != THFHE_OK) die("cannot create device context");
-    g_ctx[bk] = e;
-    return e;
+    return thfhe_ctx_create(&p, bkc.data(), ksk.data(), dev ? std::atoi(dev) : 0, &e.ctx) == THFHE_OK;
+}
+
+Cache::Ptr get_ctx(const TFheGateBootstrappingCloudKeySet *bk) {
+    Cache::Ptr s = g_cache.acquire(bk, fingerprint(bk), [&](Entry &e) { return build_ctx(bk, e); });
+    if (!s) die("cannot create device context");
+    return s;
 }
 
 // One evaluation of `count` gates of one kind on contiguous LweSample arrays.
@@ -140,32 +139,10 @@ void run_batch(const Entry &e, int op, LweSample *result, const LweSample *ca, c
     }
 }
 
-// ---- combining batcher for the single-gate entry points --------------------------------------------------------------
+// ---- combining the single-gate entry points ------------------------------------------------------------------------
 // The reference calls boots* from an OpenMP loop on a shared key set (src/KNN_medical_data.cpp:681-691).  Calls that arrive
-// while a launch is in flight are queued and evaluated TOGETHER by the next leader thread in one mixed-opcode launch
-// (thfhe_gates_mixed; MUX requests in one thfhe_gates call), so T concurrent callers cost one gate latency, not T.
-struct Request {
-    int op;
-    LweSample *result;
-    const LweSample *a, *b, *c;
-    bool done = false;
-};
-struct Batcher {
-    std::mutex m;
-    std::condition_variable cv;
-    std::vector<Request *> queue;
-    bool leader_active = false;
-};
-std::mutex g_bmu;
-std::map<const TFheGateBootstrappingCloudKeySet *, Batcher *> g_batchers;
-
-Batcher *get_batcher(const TFheGateBootstrappingCloudKeySet *bk) {
-    std::lock_guard<std::mutex> g(g_bmu);
-    auto it = g_batchers.find(bk);
-    if (it != g_batchers.end()) return it->second;
-    return g_batchers[bk] = new Batcher;
-}
-
+// while a launch is in flight are queued on the key's Slot and evaluated TOGETHER by the next leader thread in one mixed-opcode
+// launch (thfhe_gates_mixed; MUX requests in one thfhe_gates call), so T concurrent callers cost one gate latency, not T.
 void execute(const Entry &e, const std::vector<Request *> &batch) {
     const size_t rec = (size_t)e.n + 1;
     std::vector<Request *> two, mux;
@@ -206,31 +183,15 @@ void execute(const Entry &e, const std::vector<Request *> &batch) {
 }
 
 void run_one(int op, LweSample *result, const LweSample *ca, const LweSample *cb, const LweSample *cc, const TFheGateBootstrappingCloudKeySet *bk) {
-    const Entry e = get_ctx(bk);
-    Batcher *B = get_batcher(bk);
+    const Cache::Ptr e = get_ctx(bk);  // keeps context, queue, mutex and condition variable alive until this call returns
     Request r{op, result, ca, cb, cc};
-    std::unique_lock<std::mutex> lk(B->m);
-    B->queue.push_back(&r);
-    while (!r.done) {
-        if (!B->leader_active) {
-            B->leader_active = true;
-            std::vector<Request *> batch;
-            batch.swap(B->queue);
-            lk.unlock();
-            if (!batch.empty()) execute(e, batch);
-            lk.lock();
-            for (Request *q : batch) q->done = true;
-            B->leader_active = false;
-            B->cv.notify_all();
-        } else {
-            B->cv.wait(lk);
-        }
-    }
+    thfhe_slot::combine(*e, r, [](Entry &slot, const std::vector<Request *> &batch) { execute(slot, batch); });
 }
 
 void run(int op, LweSample *result, const LweSample *ca, const LweSample *cb, const LweSample *cc, int count,
          const TFheGateBootstrappingCloudKeySet *bk) {
-    run_batch(get_ctx(bk), op, result, ca, cb, cc, count);
+    const Cache::Ptr e = get_ctx(bk);
+    run_batch(*e, op, result, ca, cb, cc, count);
 }
 
 }  // namespace
@@ -282,28 +243,8 @@ int thfhe_tfhe_gate_batch(int op, LweSample *result, const LweSample *ca, const 
     return THFHE_OK;
 }
 void thfhe_tfhe_forget_key(const TFheGateBootstrappingCloudKeySet *bk) {
-    // first retire the batcher: wait until no leader is executing on this key's context and nobody is queued
-    Batcher *B = nullptr;
-    {
-        std::lock_guard<std::mutex> g(g_bmu);
-        auto it = g_batchers.find(bk);
-        if (it != g_batchers.end()) {
-            B = it->second;
-            g_batchers.erase(it);
-        }
-    }
-    if (B) {
-        {
-            std::unique_lock<std::mutex> lk(B->m);
-            B->cv.wait(lk, [&] { return !B->leader_active && B->queue.empty(); });
-        }
-        delete B;
-    }
-    std::lock_guard<std::mutex> g(g_mu);
-    auto it = g_ctx.find(bk);
-    if (it != g_ctx.end()) {
-        thfhe_ctx_destroy(it->second.ctx);
-        g_ctx.erase(it);
-    }
+    // drops the cache's reference: the device context is destroyed now, or -- if calls on this key set are still running -- by the
+    // last of them when it returns (thfhe_keyslot.h); later calls with this address build a fresh context
+    g_cache.forget(bk);
 }
 }

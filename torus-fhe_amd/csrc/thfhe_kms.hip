@@ -627,15 +627,13 @@ int kms_finish(thfhe_kms_ctx *c) {
     return THFHE_OK;
 }
 // the whole gate / bootstrap on device buffers; x (and y) int32[G][P n + 1] on the host
-int kms_bootstrap_impl(thfhe_kms_ctx *c, int32_t cb, int32_t cx, int32_t cy, int64_t mu, const int32_t *x, const int32_t *y, int32_t *u_out, int32_t *out,
-                       size_t G, int fast_boot) {
+int kms_bootstrap_body(thfhe_kms_ctx *c, KmsTables &tabs, int32_t cb, int32_t cx, int32_t cy, int64_t mu, const int32_t *x, const int32_t *y, int32_t *u_out,
+                       int32_t *out, size_t G, int fast_boot) {
     typedef thfhe_kms_ctx K;
     if (!c->d_relin) return thfhe_fail(THFHE_E_INVALID, "thfhe_kms_set_relin_keys has not been called on this context");
     const int P = c->p.parties, n = c->p.n, lv = c->p.l_lev;
     const size_t N = 2048, words = (size_t)P * n + 1, uw = (size_t)P * N + 1;
-    std::lock_guard<std::mutex> lock(c->mu);
     THFHE_HIP(hipSetDevice(c->device));
-    KmsTables tabs;
     int rc = kms_w(c, K::W_X, G * words * 4);
     if (!rc && y) rc = kms_w(c, K::W_Y, G * words * 4);
     if (!rc) rc = kms_w(c, K::W_BARA, (size_t)P * G * n * 4);
@@ -685,6 +683,32 @@ int kms_bootstrap_impl(thfhe_kms_ctx *c, int32_t cb, int32_t cx, int32_t cy, int
     }
     return kms_finish(c);
 }
+// Every failure leaves through here: asynchronous copies still queued read the host tables in `tabs` and write the caller's buffers,
+// so the stream is drained before `tabs` dies and before the call reports failure.
+int kms_bootstrap_impl(thfhe_kms_ctx *c, int32_t cb, int32_t cx, int32_t cy, int64_t mu, const int32_t *x, const int32_t *y, int32_t *u_out, int32_t *out,
+                       size_t G, int fast_boot) {
+    std::lock_guard<std::mutex> lock(c->mu);
+    KmsTables tabs;
+    const int rc = kms_bootstrap_body(c, tabs, cb, cx, cy, mu, x, y, u_out, out, G, fast_boot);
+    if (rc) (void)hipStreamSynchronize(c->stream);
+    return rc;
+}
+int kms_lev_rlwe_mul_body(thfhe_kms_ctx *c, KmsTables &tabs, int party, int64_t *accum, const int64_t *lev, size_t count) {
+    typedef thfhe_kms_ctx K;
+    if (!c->d_relin) return thfhe_fail(THFHE_E_INVALID, "thfhe_kms_set_relin_keys has not been called on this context");
+    THFHE_HIP(hipSetDevice(c->device));
+    const size_t N = 2048, ab = count * (c->p.parties + 1) * N * 8, lb = count * c->p.l_lev * 2 * N * 8;
+    int rc = kms_w(c, K::W_ACCUM, ab);
+    if (!rc) rc = kms_w(c, K::W_LEV, lb);
+    if (rc) return rc;
+    THFHE_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_w[K::W_ACCUM], accum, ab, hipMemcpyHostToDevice, c->stream));
+    THFHE_HIP(hipMemcpyAsync(c->d_w[K::W_LEV], lev, lb, hipMemcpyHostToDevice, c->stream));
+    rc = kms_lev_rlwe_mul_dev(c, tabs, party, count, (int64_t *)c->d_w[K::W_ACCUM], (const int64_t *)c->d_w[K::W_LEV]);
+    if (rc) return rc;
+    THFHE_HIP(hipMemcpyAsync(accum, c->d_w[K::W_ACCUM], ab, hipMemcpyDeviceToHost, c->stream));
+    return kms_finish(c);
+}
 }  // namespace
 
 extern "C" {
@@ -716,25 +740,14 @@ int thfhe_kms_set_relin_keys(thfhe_kms_ctx *c, const int64_t *uni, const int64_t
 }
 
 int thfhe_kms_lev_rlwe_mul(thfhe_kms_ctx *c, int party, int64_t *accum, const int64_t *lev, size_t count) {
-    typedef thfhe_kms_ctx K;
     if (!c || !accum || !lev) return thfhe_fail(THFHE_E_INVALID, "null argument");
     if (party < 0 || party >= c->p.parties) return thfhe_fail(THFHE_E_INVALID, "party out of range");
-    if (!c->d_relin) return thfhe_fail(THFHE_E_INVALID, "thfhe_kms_set_relin_keys has not been called on this context");
     if (count == 0) return THFHE_OK;
     std::lock_guard<std::mutex> lock(c->mu);
-    THFHE_HIP(hipSetDevice(c->device));
-    const size_t N = 2048, ab = count * (c->p.parties + 1) * N * 8, lb = count * c->p.l_lev * 2 * N * 8;
     KmsTables tabs;
-    int rc = kms_w(c, K::W_ACCUM, ab);
-    if (!rc) rc = kms_w(c, K::W_LEV, lb);
-    if (rc) return rc;
-    THFHE_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
-    THFHE_HIP(hipMemcpyAsync(c->d_w[K::W_ACCUM], accum, ab, hipMemcpyHostToDevice, c->stream));
-    THFHE_HIP(hipMemcpyAsync(c->d_w[K::W_LEV], lev, lb, hipMemcpyHostToDevice, c->stream));
-    rc = kms_lev_rlwe_mul_dev(c, tabs, party, count, (int64_t *)c->d_w[K::W_ACCUM], (const int64_t *)c->d_w[K::W_LEV]);
-    if (rc) return rc;
-    THFHE_HIP(hipMemcpyAsync(accum, c->d_w[K::W_ACCUM], ab, hipMemcpyDeviceToHost, c->stream));
-    return kms_finish(c);
+    const int rc = kms_lev_rlwe_mul_body(c, tabs, party, accum, lev, count);
+    if (rc) (void)hipStreamSynchronize(c->stream);   // queued copies still read `tabs` / write the caller's buffer
+    return rc;
 }
 
 int thfhe_kms_bootstrap(thfhe_kms_ctx *c, int64_t mu, const int32_t *x, int32_t *u, int32_t *out, size_t count, int fast_boot) {

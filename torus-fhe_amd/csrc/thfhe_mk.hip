@@ -679,8 +679,8 @@ __global__ __launch_bounds__(256) void mk_extract_kernel(const int64_t *__restri
     }
 }
 
-// party-sharded prologue: the gate's linear part + mod-switch for ONE party's n mask words (record words
-// [first_word, first_word + n)) and for b.  Records have rec_words = P_total * n + 1 words.
+// party-sharded prologue: the gate's linear part + mod-switch for the n mask words of this context's block of parties (record
+// words [first_word, first_word + n), n = parties_of_this_context * n_lwe) and for b.  Records have rec_words = P_total * n_lwe + 1 words.
 __global__ __launch_bounds__(256) void mk_prologue_slice_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ in1,
                                                                  const int32_t *__restrict__ in2, MKLin L, int rec_words, int first_word, int n,
                                                                  int log2_2n, long jobs, int32_t *__restrict__ bara, int32_t *__restrict__ barb) {
@@ -764,10 +764,11 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     c->log2_2n = ilog2(2 * p->N);
     c->parts = parts;
     c->pw = pw;
-    int64_t *d_coeff = nullptr;  // upload staging, freed on every path
+    int64_t *d_coeff = nullptr, *d_exp = nullptr;  // upload staging, freed on every path
     int32_t *d_raw = nullptr;
     auto fail = [&](int code) {
         (void)hipFree(d_coeff);
+        (void)hipFree(d_exp);
         (void)hipFree(d_raw);
         thfhe_mk_ctx_destroy(c);
         return code;
@@ -800,7 +801,6 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     CK(hipMalloc(&c->d_bk, chunks * (p->N / 2) * sizeof(cplx)));
     if (p->N == 2048) {
         if (parts > 1) {   // key rows followed by their copies shifted left by pw, 2 pw bits (wrapping): d (*) K = sum_w d_w (*) (K << pw w)
-            int64_t *d_exp = nullptr;
             CK(hipMalloc(&d_exp, coeff_words * parts * sizeof(int64_t)));
             const long polys = PN * 4 * p->l;
             hipLaunchKernelGGL(mk_expand_parts_kernel, dim3((unsigned)polys, (unsigned)parts), dim3(256), 0, c->stream, d_coeff, d_exp, p->l, parts, pw);
@@ -808,6 +808,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
             CK(hipStreamSynchronize(c->stream));
             (void)hipFree(d_coeff);
             d_coeff = d_exp;
+            d_exp = nullptr;
         }
         const long items = PN * 2 * le * 8;
         hipLaunchKernelGGL(mk_key_transform_2k_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, c->stream, d_coeff, PN, le, c->d_tw, c->d_bk);
@@ -1031,11 +1032,12 @@ int thfhe_mk_prologue_dev(thfhe_mk_ctx *c, int op, int which, const int32_t *d0,
     if (op == -1) op = kOpIdentity;  // plain bootstrap of in0
     if (!mk_gate_lin(op, which, L)) return thfhe_fail(THFHE_E_INVALID, "gate not defined for the 3-gen multi-key scheme");
     if ((L.cy != 0 && !d1) || (L.cz != 0 && !d2)) return thfhe_fail(THFHE_E_INVALID, "null operand");
-    if (first_word < 0 || first_word + c->p.n > rec_words - 1) return thfhe_fail(THFHE_E_INVALID, "party slice outside the record");
+    const int nw = c->words;  // this context's parties are contiguous in the record: parties * n mask words
+    if (first_word < 0 || first_word + nw > rec_words - 1) return thfhe_fail(THFHE_E_INVALID, "party slice outside the record");
     std::lock_guard<std::mutex> g(c->mu);
     THFHE_HIP(hipSetDevice(c->device));
-    const dim3 grid((unsigned)((c->p.n + 1 + 255) / 256), (unsigned)count);
-    hipLaunchKernelGGL(mk_prologue_slice_kernel, grid, dim3(256), 0, c->stream, d0, d1, d2, L, rec_words, first_word, c->p.n, c->log2_2n, (long)count, d_bara, d_barb);
+    const dim3 grid((unsigned)((nw + 1 + 255) / 256), (unsigned)count);
+    hipLaunchKernelGGL(mk_prologue_slice_kernel, grid, dim3(256), 0, c->stream, d0, d1, d2, L, rec_words, first_word, nw, c->log2_2n, (long)count, d_bara, d_barb);
     THFHE_HIP(hipGetLastError());
     return THFHE_OK;
 }

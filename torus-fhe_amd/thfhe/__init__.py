@@ -58,6 +58,29 @@ PARAM_SETS = {
 }
 
 
+# Noise standard deviations of the reference's parameter sets (lwe = fresh ciphertexts and key-switch key, bk = bootstrapping key):
+# api.jl:76-115, mk_api.jl:4-10,32-38,44-50,56-62,84-90,98-104,111-117,140-146,214-220,246-252,268-274,292-298; SK-lib = libthfhe.cpp:316-338.
+# MK4-N2048 (BASELINE.json configs[4] wording) inherits the 4-party set's.  Indexed with [] on purpose: an unknown set must raise.
+SIGMAS = {
+    "SK-80": dict(lwe=2.0**-15, bk=9.0e-9, ks=2.44e-5),
+    "SK-128": dict(lwe=2.0**-15, bk=2.0**-25, ks=2.0**-15),
+    "SK-lib": dict(lwe=2.0**-15, bk=2.0**-25, ks=2.0**-15),
+    "MK2": dict(lwe=2.0**-13.52, bk=2.0**-30.70, ks=2.0**-13.52),
+    "MK3": dict(lwe=2.0**-13.26, bk=2.0**-30.70, ks=2.0**-13.26),
+    "MK4": dict(lwe=2.0**-13.26, bk=2.0**-30.70, ks=2.0**-13.26),
+    "MK5": dict(lwe=2.0**-13.52, bk=2.0**-30.70, ks=2.0**-13.52),
+    "MK8": dict(lwe=2.0**-14.04, bk=2.0**-30.70, ks=2.0**-14.04),
+    "MK4-N2048": dict(lwe=2.0**-13.26, bk=2.0**-30.70, ks=2.0**-13.26),
+    "MK16": dict(lwe=2.0**-15.34, bk=2.0**-62.0, ks=2.0**-15.34),
+    "MK32": dict(lwe=2.0**-16.12, bk=2.0**-62.0, ks=2.0**-16.12),
+    "MK64": dict(lwe=2.0**-16.90, bk=2.0**-62.0, ks=2.0**-16.90),
+    "MK128": dict(lwe=2.0**-17.42, bk=2.0**-62.0, ks=2.0**-17.42),
+    "CCS2": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
+    "CCS4": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
+    "CCS8": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
+}
+
+
 class KmsParams(C.Structure):
     """thfhe_kms_params (include/thfhe_hip.h): the KMS scheme (mk_bootstrap_new) has three gadget families -- gsw (per-party TGSW blind
     rotation of the TLev accumulator), lev (the TLev accumulator), uni (uni-encryption / public keys) -- on a Torus64 ring."""
@@ -358,6 +381,12 @@ class CloudKey:
     def set_coop_threshold(self, max_jobs):
         """Batches of <= max_jobs rotations use the cooperative latency kernel; 0 forces the LDS-ring kernel."""
         _check(lib().thfhe_set_coop_threshold(self.h, int(max_jobs)))
+        self._coop_threshold = int(max_jobs)
+
+    def rotation_kernel_name(self, rotations):
+        """The blind-rotation kernel a batch of `rotations` is dispatched to (thfhe_sk.hip launch logic; for profiles and bench.py)."""
+        l = self.params.l
+        return f"sk_blind_rotate_ring_kernel<{l}>" if rotations > getattr(self, "_coop_threshold", 1024) else f"sk_blind_rotate_coop_kernel<{l}>"
 
     def set_profiling(self, on):
         _check(lib().thfhe_set_profiling(self.h, int(bool(on))))
@@ -492,6 +521,15 @@ class MKCloudKey:
     def set_pair_threshold(self, max_single_jobs):
         """Batches of <= max_single_jobs rotations run one gate per workgroup; larger ones two gates per workgroup."""
         _check(lib().thfhe_mk_set_pair_threshold(self.h, int(max_single_jobs)))
+        self._pair_threshold = int(max_single_jobs)
+
+    def rotation_kernel_name(self, rotations):
+        """The blind-rotation kernel a batch of `rotations` is dispatched to (mk_launch_rotation in thfhe_mk.hip)."""
+        p = self.params
+        if p.N == 2048:
+            return f"mk_blind_rotate_coop2k_kernel<{p.l * (((p.Bgbit + 8) // 9) if p.Bgbit > 10 else 1)}>"
+        pair = p.l <= 3 and rotations > getattr(self, "_pair_threshold", 256)
+        return f"mk_blind_rotate_{'pair' if pair else 'coop'}_kernel<{p.l}>"
 
     def last_timings(self):
         ms = (C.c_float * 4)()

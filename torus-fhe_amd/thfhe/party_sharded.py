@@ -1,8 +1,9 @@
 """Party-sharded 3-gen multi-key bootstrap (the north-star's "RCCL accumulator combine").
 
-One rank per party: rank p holds ONLY party p's TransformedBootstrapKeyPart_3gen and KeyswitchKey (a `parties = 1`
-thfhe_mk_ctx).  The reference's blind rotation is party-major on one accumulator (3gen_mk_internals.jl:78-84), so the
-accumulator travels down the ranks as a pipeline:
+The parties' keys are dealt over the ranks of a pipeline group: with W ranks and P parties (W divides P) rank r holds ONLY
+the TransformedBootstrapKeyPart_3gen and KeyswitchKey of parties [r P/W, (r+1) P/W) (a `parties = P/W` thfhe_mk_ctx; W = P
+is one rank per party).  The reference's blind rotation is party-major on one accumulator (3gen_mk_internals.jl:78-84), so
+the accumulator travels down the ranks as a pipeline (shown for W = P):
 
     rank 0   acc = X^{-barb} mu ; n CMuxes with party 0's key       --send-->  rank 1   n CMuxes with party 1's key  --> ...
     rank P-1 rlwe_extract_sample_64 + t64tot32 (rlwe.jl:70-74)       --broadcast u (LWE of dimension N)-->  every rank
@@ -28,23 +29,43 @@ from . import AND, AND3, MU8_64, MUX, NAND, NOT, COPY, OR, XOR, MKCloudKey, Thfh
 E8 = 1 << 29
 
 
+def party_topology(world, parties, rank=0):
+    """How `world` ranks share the party pipeline of a P-party key set: pipeline groups of W = min(world, P) ranks (W must divide
+    P and world), every group evaluates its own gate batch; rank r of a group holds parties [r P/W, (r+1) P/W).
+    Returns dict(group_size, groups, group, group_rank, parties=(first, last+1), group_ranks=[global ranks of this rank's group])."""
+    W = min(world, parties)
+    if world < 1 or parties % W or world % W:
+        raise ValueError(f"party-sharded mode: {world} rank(s) cannot share {parties} parties (need min(world, P) | P and | world)")
+    g, r, m = rank // W, rank % W, parties // W
+    return dict(group_size=W, groups=world // W, group=g, group_rank=r, parties=(r * m, (r + 1) * m),
+                group_ranks=list(range(g * W, (g + 1) * W)))
+
+
 class HipPartyBackend:
-    """Party p's kernels on one MI355X: thfhe_mk_{prologue,rotate_partial,extract,keyswitch}_dev on torch device tensors."""
+    """The kernels of a contiguous block of parties on one MI355X: thfhe_mk_{prologue,rotate_partial,extract,keyswitch}_dev on
+    torch device tensors."""
 
     def __init__(self, params, party, bk_part, ksk_part, device=0):
-        """params: the FULL parameter set (parties = P); bk_part int64[n][4][l][N]; ksk_part int32[N][t][base-1][n+1]."""
+        """params: the FULL parameter set (parties = P).  party: an index p (then bk_part int64[n][4][l][N], ksk_part
+        int32[N][t][base-1][n+1]) or a range (first, last+1) (then bk_part / ksk_part carry a leading axis over those parties)."""
         if not torch.cuda.is_available():
             raise ThfheError("HipPartyBackend needs a HIP device (there is no CPU fallback)")
-        self.params, self.party = params, party
+        if isinstance(party, int):
+            party, bk_part, ksk_part = (party, party + 1), np.asarray(bk_part)[None], np.asarray(ksk_part)[None]
+        self.params, self.first, self.count = params, int(party[0]), int(party[1] - party[0])
+        self.party = self.first
+        if not (0 <= self.first and self.count >= 1 and self.first + self.count <= params.parties) or len(bk_part) != self.count or len(ksk_part) != self.count:
+            raise ValueError("party range outside the parameter set, or key parts that do not match it")
         self.device = torch.device("cuda", device)
         d = params.as_dict()
-        d["parties"] = 1
-        self.ck = MKCloudKey(make_params(**d), np.asarray(bk_part)[None], np.asarray(ksk_part)[None], device)
+        d["parties"] = self.count
+        self.ck = MKCloudKey(make_params(**d), np.asarray(bk_part), np.asarray(ksk_part), device)
         # kernels, torch's tensor plumbing and the RCCL collectives are all ordered on ONE side stream owned by this backend
         # (torch's default stream has the null handle, which thfhe_mk_set_stream reads as "the context's own stream")
         self.stream = torch.cuda.Stream(self.device)
         _check(lib().thfhe_mk_set_stream(self.ck.h, C.c_void_p(self.stream.cuda_stream)))
         self.rec_words = params.parties * params.n + 1
+        self.timing = None   # a list: (start, end) torch events around every rotation launch, on this backend's stream (bench.py)
 
     def stream_context(self):
         return torch.cuda.stream(self.stream)
@@ -58,18 +79,24 @@ class HipPartyBackend:
     def prologue(self, op, which, x, y, z):
         p = self.params
         count = x.shape[0]
-        bara, barb = self.empty((count, p.n), torch.int32), self.empty((count,), torch.int32)
+        bara, barb = self.empty((count, self.count * p.n), torch.int32), self.empty((count,), torch.int32)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        _check(lib().thfhe_mk_prologue_dev(self.ck.h, op, which, ptr(x), ptr(y), ptr(z), self.rec_words, self.party * p.n,
+        _check(lib().thfhe_mk_prologue_dev(self.ck.h, op, which, ptr(x), ptr(y), ptr(z), self.rec_words, self.first * p.n,
                                            ptr(bara), ptr(barb), count))
         return bara, barb
 
     def rotate(self, bara, barb, mu, acc_in):
         count = bara.shape[0]
         acc = self.empty((count, 2, self.params.N), torch.int64)
+        if self.timing is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(self.stream)
         _check(lib().thfhe_mk_rotate_partial_dev(self.ck.h, C.c_void_p(bara.data_ptr()), C.c_void_p(barb.data_ptr()), mu,
                                                  C.c_void_p(acc_in.data_ptr()) if acc_in is not None else None,
                                                  C.c_void_p(acc.data_ptr()), count))
+        if self.timing is not None:
+            ev1.record(self.stream)
+            self.timing.append((ev0, ev1))
         return acc
 
     def extract(self, acc):
@@ -78,13 +105,14 @@ class HipPartyBackend:
         return u
 
     def keyswitch(self, u):
-        out = self.empty((u.shape[0], self.params.n + 1), torch.int32)
+        out = self.empty((u.shape[0], self.count * self.params.n + 1), torch.int32)
         _check(lib().thfhe_mk_keyswitch_dev(self.ck.h, C.c_void_p(u.data_ptr()), C.c_void_p(out.data_ptr()), u.shape[0]))
         return out
 
 
 class PartyShardedEvaluator:
-    """mk_bootstrap_3gen / mk_gate_*_3gen with the parties' keys sharded over the ranks of `group` (world size = P).
+    """mk_bootstrap_3gen / mk_gate_*_3gen with the parties' keys sharded over the W ranks of `group` (W divides P; rank r holds
+    parties [r P/W, (r+1) P/W), see party_topology).  W = 1 (no process group at all) runs the same pieces on one GPU.
 
     Inputs are full MK records int32[count][P*n+1] (every party sees the ciphertexts, as in the reference); they must live
     on the backend's device.  Every rank returns the full output records.
@@ -92,11 +120,15 @@ class PartyShardedEvaluator:
 
     def __init__(self, params, backend, group=None, pipeline_chunks=4):
         self.params, self.be, self.group = params, backend, group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        if self.world != params.parties:
-            raise ValueError(f"party-sharded mode needs one rank per party (world {self.world}, parties {params.parties})")
+        self.solo = group is None and not (dist.is_available() and dist.is_initialized())
+        self.rank, self.world = (0, 1) if self.solo else (dist.get_rank(group), dist.get_world_size(group))
+        if params.parties % self.world:
+            raise ValueError(f"party-sharded mode needs a rank count that divides the parties (world {self.world}, parties {params.parties})")
+        self.per_rank = params.parties // self.world
+        if getattr(backend, "count", 1) != self.per_rank or getattr(backend, "first", self.rank) != self.rank * self.per_rank:
+            raise ValueError("the backend does not hold this rank's block of parties")
         self.chunks = max(1, int(pipeline_chunks))
-        self.host_staged = dist.get_backend(group) != "nccl"
+        self.host_staged = (not self.solo) and dist.get_backend(group) != "nccl"
 
     # -- transport (RCCL moves device tensors; gloo goes through host memory) --------------------------------------------
     def _send(self, t, dst):
@@ -108,11 +140,15 @@ class PartyShardedEvaluator:
         return buf.to(self.be.device) if self.host_staged else buf
 
     def _broadcast(self, t, src):
+        if self.world == 1:
+            return t
         buf = t.cpu() if self.host_staged else t
         dist.broadcast(buf, dist.get_global_rank(self.group, src) if self.group else src, group=self.group)
         return buf.to(self.be.device) if self.host_staged else buf
 
     def _all_gather(self, t):
+        if self.world == 1:
+            return [t]
         t = t.cpu().contiguous() if self.host_staged else t.contiguous()
         parts = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(parts, t, group=self.group)
@@ -149,12 +185,13 @@ class PartyShardedEvaluator:
             u = u.clone()
             u[:, p.N] = 0
         parts = self._all_gather(be.keyswitch(u))
-        out = be.empty((jobs, P * p.n + 1), torch.int32)
+        m = self.per_rank * p.n   # mask words per rank: out.a[:, parties of rank q] = part_q.a ; out.b = u.b + sum part.b
+        out = be.empty((jobs, p.parties * p.n + 1), torch.int32)
         b = torch.zeros((jobs,), dtype=torch.int64, device=out.device)
         for q, part in enumerate(parts):
-            out[:, q * p.n:(q + 1) * p.n] = part[:, :p.n]
-            b += part[:, p.n].to(torch.int64)
-        out[:, P * p.n] = b.to(torch.int32)  # wraps mod 2^32
+            out[:, q * m:(q + 1) * m] = part[:, :m]
+            b += part[:, m].to(torch.int64)
+        out[:, p.parties * p.n] = b.to(torch.int32)  # wraps mod 2^32
         return out
 
     def _on_stream(self):
