@@ -100,83 +100,6 @@ struct WaveQ {  // third-generation ring kernel: as WaveR, first transpose in re
         for (int l = 0; l < 64; l++) invq_seg3(z[l], base.r[l]);
     }
 };
-// host model of wave_transpose_hi3p, instruction by instruction (physical registers):
-//   row_ror:8 DPP move      lane i of a 16-lane row reads lane i ^ 8
-//   v_permlane16_swap a, b  the odd rows of a <-> the even rows of b   (partner lane ^ 16)
-//   v_permlane32_swap a, b  the upper half-wave of a <-> the lower half-wave of b
-void lanes_transpose_hi3p(cplx (*z)[8]) {
-    static cplx t[64][8];
-    memcpy(t, z, sizeof(t));
-    for (int l = 0; l < 64; l++)
-        for (int r = 4; r < 8; r++) z[l][r] = t[l ^ 8][r];
-    for (int r = 0; r < 8; r++) {
-        if (r & 2) continue;
-        for (int l = 0; l < 64; l++)
-            if (l & 16) std::swap(z[l][r], z[l ^ 16][r + 2]);
-    }
-    for (int r = 0; r < 8; r += 2)
-        for (int l = 32; l < 64; l++) std::swap(z[l][r], z[l ^ 32][r + 1]);
-}
-struct WaveP {  // fifth-generation single-key transforms: exchange with flipped naming (thfhe_lane.h, variant "p"); lane l owns coefficient column lane_lam(l)
-    cplx xbuf[kXbufSlots];
-    LaneTw t[64];
-    W64 w[64];
-    LaneSg g[64];
-    WaveP() {
-        static cplx T1[512], T2[64], roots[128];
-        make_twiddles_1024(T1, T2);
-        make_lane_roots_1024(roots);
-        for (int l = 0; l < 64; l++) {
-            const int lam = lane_lam(l);
-            t[l] = make_lane_tw_p(LaneRoots{roots[2 * lam], roots[2 * lam + 1]}, l);
-            w[l] = W64{T2[8 + (l & 7)]};
-            g[l] = make_lane_sg(l);
-        }
-    }
-    void fwd(cplx (*z)[8]) {
-        for (int l = 0; l < 64; l++) fwdp_seg1(z[l], t[l], g[l]);
-        lanes_transpose_hi3p(z);
-        for (int l = 0; l < 64; l++) fwdr_seg2_st(l, z[l], xbuf, w[l]);
-        for (int l = 0; l < 64; l++) fwd_seg3(l, z[l], xbuf);
-    }
-    void inv(cplx (*z)[8]) {
-        for (int l = 0; l < 64; l++) invr_seg1(l, z[l], xbuf, w[l]);
-        for (int l = 0; l < 64; l++) {
-            inv_seg2_ld(l, z[l], xbuf);
-            dft8s<-1>(z[l], g[l]);
-        }
-        lanes_transpose_hi3p(z);
-        for (int l = 0; l < 64; l++) invp_seg3(z[l], t[l]);
-    }
-};
-struct WaveQH {  // fourth-generation ring kernel: as WaveQ, the LDS transpose through a 4.5 KiB buffer of doubles (real parts, then imaginary parts)
-    WaveR base;
-    double xr[kXhalfSlots];
-    void fwd(cplx (*z)[8]) {
-        for (int l = 0; l < 64; l++) fwdq_seg1(z[l], base.r[l]);
-        lanes_transpose_hi3(z);
-        for (int l = 0; l < 64; l++) fwdh_tw(z[l], base.w[l]);
-        for (int l = 0; l < 64; l++) xh_put_c<0>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) xh_get_d<0>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) xh_put_c<1>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) {
-            xh_get_d<1>(l, z[l], xr);
-            dft8<+1>(z[l]);
-        }
-    }
-    void inv(cplx (*z)[8]) {
-        for (int l = 0; l < 64; l++) invh_tw(z[l], base.w[l]);
-        for (int l = 0; l < 64; l++) xh_put_d<0>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) xh_get_c<0>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) xh_put_d<1>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) {
-            xh_get_c<1>(l, z[l], xr);
-            dft8<-1>(z[l]);
-        }
-        lanes_transpose_hi3(z);
-        for (int l = 0; l < 64; l++) invq_seg3(z[l], base.r[l]);
-    }
-};
 struct WaveQS {  // multi-key kernels: first transpose in registers, second through the XOR-swizzled 512-slot buffer (no room for padding)
     WaveR base;
     void fwd(cplx (*z)[8]) {
@@ -424,66 +347,11 @@ static double variant_crosscheck(const int32_t *small, const int32_t *b, int32_t
     return worst;
 }
 extern "C" {
-// variant "p" has a spectrum layout of its own (lane permutation and a per-lane sign), so it is checked on what matters: the key transformed
-// by it, the digits transformed by it, multiplied, transformed back by it and rounded with the sign-absorbing update must be the exact
-// negacyclic product.  Returns the worst distance of an inverse-transform output from an integer; *tau_ok = 1 if, in addition, the
-// spectrum equals the table variant's after the documented lane permutation and sign.
-double emu_flipped_variant_product(const int32_t *small, const int32_t *b, int32_t *out, int *layout_ok) {
-    static WaveP wp;
-    Wave w;
-    static cplx z[64][8], z2[64][8], klo[64][8], khi[64][8], slo[64][8], shi[64][8];
-    for (int l = 0; l < 64; l++) {
-        const int lam = lane_lam(l);
-        key_limbs_to_z(lam, b, klo[l], khi[l]);
-        for (int m = 0; m < 8; m++) {
-            z[l][m] = cplx{(double)small[lam + 64 * m], (double)small[lam + 64 * m + 512]};
-            z2[l][m] = cplx{(double)small[l + 64 * m], (double)small[l + 64 * m + 512]};
-        }
-    }
-    wp.fwd(klo);
-    wp.fwd(khi);
-    wp.fwd(z);
-    w.fwd(z2);
-    // documented layout: table variant lane k1 + 8 k0  ->  variant p lane k1 + 8 rev3(k0), times tau = -1 where lane bits 0 and 3 are set
-    int ok = 1;
-    for (int l = 0; l < 64; l++) {
-        const int k0 = l >> 3, rev = ((k0 & 1) << 2) | (k0 & 2) | ((k0 & 4) >> 2), lp = (l & 7) | (rev << 3);
-        const double tau = ((lp & 9) == 9) ? -1.0 : 1.0;
-        for (int m = 0; m < 8; m++)
-            if (__builtin_fabs(z[lp][m].re - tau * z2[l][m].re) + __builtin_fabs(z[lp][m].im - tau * z2[l][m].im) > 1e-6) ok = 0;
-    }
-    *layout_ok = ok;
-    memset(slo, 0, sizeof(slo));
-    memset(shi, 0, sizeof(shi));
-    for (int l = 0; l < 64; l++)
-        for (int m = 0; m < 8; m++) {
-            cfma(slo[l][m], z[l][m], cplx{klo[l][m].re * (1.0 / 512), klo[l][m].im * (1.0 / 512)});
-            cfma(shi[l][m], z[l][m], cplx{khi[l][m].re * (1.0 / 512), khi[l][m].im * (1.0 / 512)});
-        }
-    wp.inv(slo);
-    wp.inv(shi);
-    double worst = 0;
-    std::vector<int32_t> acc(1024, 0);
-    for (int l = 0; l < 64; l++) {
-        for (int m = 0; m < 8; m++)
-            for (double v : {slo[l][m].re, slo[l][m].im, shi[l][m].re, shi[l][m].im}) {
-                double d = v - __builtin_rint(v);
-                if (d < 0) d = -d;
-                if (d > worst) worst = d;
-            }
-        acc_update16p(lane_lam(l), acc.data(), slo[l], shi[l], wp.g[l].sg());
-    }
-    memcpy(out, acc.data(), sizeof(int32_t) * 1024);
-    return worst;
-}
 double emu_roots_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
     return variant_crosscheck<WaveR>(small, b, out, dmax_out);
 }
 double emu_regtranspose_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
     return variant_crosscheck<WaveQ>(small, b, out, dmax_out);
-}
-double emu_regtranspose_halfbuf_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
-    return variant_crosscheck<WaveQH>(small, b, out, dmax_out);
 }
 double emu_regtranspose_swizzled_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
     return variant_crosscheck<WaveQS>(small, b, out, dmax_out);

@@ -102,8 +102,7 @@ def test_swizzled_variant_matches_padded(E, O):
     assert np.array_equal(ref, got) and d < 1e-9
 
 
-@pytest.mark.parametrize("fn", ["emu_roots_variant_crosscheck", "emu_regtranspose_variant_crosscheck", "emu_regtranspose_swizzled_variant_crosscheck",
-                                "emu_regtranspose_halfbuf_variant_crosscheck"])
+@pytest.mark.parametrize("fn", ["emu_roots_variant_crosscheck", "emu_regtranspose_variant_crosscheck", "emu_regtranspose_swizzled_variant_crosscheck"])
 @pytest.mark.parametrize("case", ["random", "adversarial"])
 def test_roots_variant_exact_with_margin(E, O, case, fn):
     # second-generation ring kernel: pass-1 twiddles rebuilt from two per-lane roots (b * s^k0) instead of the T1 table.  The
@@ -123,24 +122,6 @@ def test_roots_variant_exact_with_margin(E, O, case, fn):
     margin = getattr(E, fn)(O.p32(a), O.p32(b), O.p32(got), C.byref(dmax))
     assert np.array_equal(ref, got)
     assert margin < 1e-4 and dmax.value < 1e-8, (margin, dmax.value)
-
-
-@pytest.mark.parametrize("case", ["random", "adversarial"])
-def test_flipped_naming_variant_exact_products_and_layout(E, O, case):
-    # variant "p" (fifth-generation single-key transforms): lane exchange with flipped naming on the lanes with bit 3 set, signs absorbed by the
-    # butterflies / the rounding step (thfhe_lane.h).  The exchange is modelled instruction by instruction on physical registers.
-    E.emu_flipped_variant_product.restype = C.c_double
-    rng = np.random.default_rng(28)
-    if case == "random":
-        a = rng.integers(-512, 512, 1024).astype(np.int32); b = rng.integers(-2**31, 2**31, 1024).astype(np.int32)
-    else:
-        a = (rng.integers(0, 2, 1024) * 1023 - 512).astype(np.int32); b = np.where(rng.integers(0, 2, 1024) == 1, 2**31 - 1, -2**31).astype(np.int32)
-    ref, got = np.zeros(1024, np.int32), np.zeros(1024, np.int32)
-    O.lib().oracle_polymul_schoolbook32(O.p32(a), O.p32(b), 1024, O.p32(ref))
-    layout_ok = C.c_int(0)
-    margin = E.emu_flipped_variant_product(O.p32(a), O.p32(b), O.p32(got), C.byref(layout_ok))
-    assert np.array_equal(ref, got)
-    assert margin < 1e-4 and layout_ok.value == 1, (margin, layout_ok.value)
 
 
 def test_fused_rotated_digits_match_reference_form(E):

@@ -187,81 +187,6 @@ __device__ __forceinline__ void wave_fft_inv_q(int lane, cplx (&z)[8], cplx *xb,
     wave_transpose_hi3(z);
     invq_seg3(z, r);
 }
-// variant "p" (thfhe_lane.h): the exchange with flipped naming on the lanes with bit 3 set -- 16 unmasked row_ror:8 moves, 16
-// v_permlane16_swap (register bit 1 <-> lane bit 4), 16 v_permlane32_swap (register bit 0 <-> lane bit 5).  Its own inverse.
-__device__ __forceinline__ void wave_transpose_hi3p(cplx (&z)[8]) {
-    uint32_t w[8][4];
-#pragma unroll
-    for (int r = 0; r < 8; r++) __builtin_memcpy(w[r], &z[r], 16);
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-#pragma unroll
-        for (int r = 4; r < 8; r++) w[r][d] = __builtin_amdgcn_update_dpp(w[r][d], w[r][d], 0x128, 0xF, 0xF, false);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            if (r & 2) continue;
-            auto q = __builtin_amdgcn_permlane16_swap(w[r][d], w[r + 2][d], false, false);
-            w[r][d] = q[0];
-            w[r + 2][d] = q[1];
-        }
-#pragma unroll
-        for (int r = 0; r < 8; r += 2) {
-            auto q = __builtin_amdgcn_permlane32_swap(w[r][d], w[r + 1][d], false, false);
-            w[r][d] = q[0];
-            w[r + 1][d] = q[1];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 8; r++) __builtin_memcpy(&z[r], w[r], 16);
-}
-__device__ __forceinline__ void wave_fft_fwd_p(int lane, cplx (&z)[8], cplx *xb, const LaneTw &t, const W64 &w, const LaneSg &g) {
-    fwdp_seg1(z, t, g);
-    wave_transpose_hi3p(z);
-    wave_sync();
-    fwdr_seg2_st(lane, z, xb, w);
-    wave_sync();
-    fwd_seg3(lane, z, xb);
-}
-__device__ __forceinline__ void wave_fft_inv_p(int lane, cplx (&z)[8], cplx *xb, const LaneTw &t, const W64 &w, const LaneSg &g) {
-    wave_sync();
-    invr_seg1(lane, z, xb, w);
-    wave_sync();
-    inv_seg2_ld(lane, z, xb);
-    dft8s<-1>(z, g);
-    wave_transpose_hi3p(z);
-    invp_seg3(z, t);
-}
-// variant "qh": first transpose in registers, second through a 4.5 KiB buffer of doubles, real parts then imaginary parts (thfhe_lane.h)
-template <class Roots>
-__device__ __forceinline__ void wave_fft_fwd_qh(int lane, cplx (&z)[8], double *xr, const Roots &r, const W64 &w) {
-    fwdq_seg1(z, r);
-    wave_transpose_hi3(z);
-    fwdh_tw(z, w);
-    wave_sync();
-    xh_put_c<0>(lane, z, xr);
-    wave_sync();
-    xh_get_d<0>(lane, z, xr);
-    wave_sync();
-    xh_put_c<1>(lane, z, xr);
-    wave_sync();
-    xh_get_d<1>(lane, z, xr);
-    dft8<+1>(z);
-}
-template <class Roots>
-__device__ __forceinline__ void wave_fft_inv_qh(int lane, cplx (&z)[8], double *xr, const Roots &r, const W64 &w) {
-    invh_tw(z, w);
-    wave_sync();
-    xh_put_d<0>(lane, z, xr);
-    wave_sync();
-    xh_get_c<0>(lane, z, xr);
-    wave_sync();
-    xh_put_d<1>(lane, z, xr);
-    wave_sync();
-    xh_get_c<1>(lane, z, xr);
-    dft8<-1>(z);
-    wave_transpose_hi3(z);
-    invq_seg3(z, r);
-}
 // variant "qs" (multi-key kernels, whose LDS has no room for padded buffers): first transpose in registers, pass-1 twiddles from the
 // per-lane roots, second transpose through the XOR-swizzled 512-slot buffer -- one LDS crossing and no T1 table reads per transform
 template <class Roots>

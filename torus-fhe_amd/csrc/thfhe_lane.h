@@ -373,126 +373,6 @@ THFHE_FN void invq_seg3(cplx (&z)[8], const LaneTw &t) {
     for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
 }
 
-// ---- variant "p": the register <-> lane exchange of variant "q" with the lane-bit-3 stage at a third of its cost.
-// In "q" the stage that exchanges a register-index bit with lane bit 3 costs three instructions per register pair and dword (two masked
-// row_ror:8 DPP moves + a copy: both moves need the pair's original values), 48 of the exchange's 80 instructions.  Here every lane SENDS
-// the same physical registers (4..7) and receives into them -- one unmasked row_ror:8 move per dword, 16 instructions -- because the lanes
-// with bit 3 set hold the pair (k, k + 4) the other way round ("flipped naming": physical register k holds logical k ^ 4).  That costs
-// nothing to produce and nothing to consume:
-//   * produced by the LAST butterfly stage of the 8-point DFT in front of the exchange, which forms the pairs y[k], y[k+4] = e +- o: with a
-//     per-lane sign sg = -1 on those lanes it is fma(sg, o, e) / fma(-sg, o, e) instead of add / sub (same instruction count, same value);
-//   * consumed by per-register twiddle multiplications whose constants are per-lane anyway (the flipped lanes load them pair-swapped) and by
-//     the FIRST stage of the next 8-point DFT, where input pairs (n, n + 4) the other way round only change the sign of the odd outputs:
-//     y'[k] = (-1)^k y[k].  In the forward transform that sign ends as a per-lane sign tau = -1 on lanes with bits 0 and 3 set on the whole
-//     spectrum -- digits and key carry it alike (the key is transformed by this code), the products do not; in the inverse transform it is
-//     (-1)^m on the flipped lanes and is absorbed by the rounding step (fma(x, sg, magic) instead of x + magic).
-// For the pairs (k, k + 4) to be the ones the exchange moves, lane bit 3 must carry the most significant bit of the pass-2 index j1: the
-// lane owns the coefficients lam + 64 m with lam = j0 + 8 j1, (j1 bit 2, bit 1, bit 0) = lane bits (3, 4, 5).  Lane bits 4 / 5 are
-// exchanged with register bits 1 / 0 by v_permlane16_swap / v_permlane32_swap as before.  Spectra: lane = k1 + 8 rev3(k0), register k2,
-// times tau -- a layout of its own, used by the single-key kernels (ring, cooperative, key transform) consistently.
-THFHE_FN int lane_lam(int lane) { return (lane & 0x17) | ((lane & 8) << 2) | ((lane & 32) >> 2); }
-struct LaneSg {
-    uint32_t flip;  // 0x80000000 on lanes with bit 3 set, else 0: XORed into the high word of 1.0 / sqrt(1/2) where the signed constants are
-                    // needed (one integer instruction each) -- kept as one VGPR because the ring kernel has no registers to spare
-    THFHE_FN double sg() const { return mk(0x3FF00000u); }                 // +-1
-    THFHE_FN double rs() const { return mk(0x3FE6A09Eu, 0x667F3BCDu); }    // +-0.70710678118654752440
-    THFHE_FN double mk(uint32_t hi, uint32_t lo = 0) const {
-        const uint64_t b = ((uint64_t)(hi ^ flip) << 32) | lo;
-        double d;
-        __builtin_memcpy(&d, &b, 8);
-        return d;
-    }
-};
-THFHE_FN LaneSg make_lane_sg(int lane) { return LaneSg{(lane & 8) ? 0x80000000u : 0u}; }
-// dft8 whose last stage writes the pairs (k, k + 4) the other way round on the lanes with sg = -1
-template <int S>
-THFHE_FN void dft8s(cplx (&y)[8], const LaneSg &g) {
-    cplx t0 = cadd(y[0], y[4]), t1 = csub(y[0], y[4]);
-    cplx t2 = cadd(y[2], y[6]), t3 = mul_si<S>(csub(y[2], y[6]));
-    cplx e0 = cadd(t0, t2), e1 = cadd(t1, t3), e2 = csub(t0, t2), e3 = csub(t1, t3);
-    cplx u0 = cadd(y[1], y[5]), u1 = csub(y[1], y[5]);
-    cplx u2 = cadd(y[3], y[7]), u3 = mul_si<S>(csub(y[3], y[7]));
-    cplx o0 = cadd(u0, u2), o1 = cadd(u1, u3), o2 = csub(u0, u2), o3 = csub(u1, u3);
-    cplx p1 = S > 0 ? cplx{o1.re - o1.im, o1.re + o1.im} : cplx{o1.re + o1.im, o1.im - o1.re};
-    cplx p3 = S > 0 ? cplx{-o3.re - o3.im, o3.re - o3.im} : cplx{o3.im - o3.re, -o3.re - o3.im};
-    cplx q2 = mul_si<S>(o2);
-    const double sg = g.sg(), rs = g.rs();
-    y[0] = cplx{__builtin_fma(sg, o0.re, e0.re), __builtin_fma(sg, o0.im, e0.im)};
-    y[4] = cplx{__builtin_fma(-sg, o0.re, e0.re), __builtin_fma(-sg, o0.im, e0.im)};
-    y[1] = cplx{__builtin_fma(rs, p1.re, e1.re), __builtin_fma(rs, p1.im, e1.im)};
-    y[5] = cplx{__builtin_fma(-rs, p1.re, e1.re), __builtin_fma(-rs, p1.im, e1.im)};
-    y[2] = cplx{__builtin_fma(sg, q2.re, e2.re), __builtin_fma(sg, q2.im, e2.im)};
-    y[6] = cplx{__builtin_fma(-sg, q2.re, e2.re), __builtin_fma(-sg, q2.im, e2.im)};
-    y[3] = cplx{__builtin_fma(rs, p3.re, e3.re), __builtin_fma(rs, p3.im, e3.im)};
-    y[7] = cplx{__builtin_fma(-rs, p3.re, e3.re), __builtin_fma(-rs, p3.im, e3.im)};
-}
-// pass-1 twiddles b s^k0 of coefficient column lam, even ones kept (LaneTw), pair-swapped (k0 <-> k0 ^ 4, i.e. e[j] <-> e[j ^ 2]) on the flipped lanes
-THFHE_FN LaneTw make_lane_tw_p(const LaneRoots &r, int lane) {
-    LaneTw t = make_lane_tw(r);
-    if (lane & 8) {
-        const cplx a = t.e[0], b = t.e[1];
-        t.e[0] = t.e[2];
-        t.e[1] = t.e[3];
-        t.e[2] = a;
-        t.e[3] = b;
-    }
-    return t;
-}
-THFHE_FN void fwdp_seg1(cplx (&z)[8], const LaneTw &t, const LaneSg &g) {
-#pragma unroll
-    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
-    dft8s<+1>(z, g);
-    const cplx s = opaque_cplx(t.s);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        z[2 * j] = cmul(z[2 * j], t.e[j]);
-        z[2 * j + 1] = cmul(z[2 * j + 1], cmul(t.e[j], s));
-    }
-}
-// inverse pass 1; returns 512 p with the sign (-1)^m on the flipped lanes (the caller's rounding step absorbs it)
-THFHE_FN void invp_seg3(cplx (&z)[8], const LaneTw &t) { invq_seg3(z, t); }
-// ---- variant "qh": as "q", but the LDS transpose (register index <-> lane bits 0..2) moves the real parts and then the imaginary
-// parts through ONE 4.5 KiB buffer of doubles instead of whole complex numbers through a 9 KiB buffer: the same padded slot maps on
-// 8-byte elements (conflict-free for ds_write_b64: 16 contiguous lanes cover the 32 banks once; for ds_read_b64: 32 lanes cover the 64
-// banks once -- xs_c / xs_d at stride 9 slots = 18 dwords), the same LDS-array cycles (16 B per lane and direction either way).  One
-// wavefront's DS instructions execute in issue order, so the imaginary parts may be written right behind the reads of the real parts
-// (no round trip in between).  The 36 KiB this frees in the ring kernel buy a key ring of six slots instead of three.
-constexpr int kXhalfSlots = 8 * 72;  // doubles (4608 B)
-THFHE_FN void fwdh_tw(cplx (&z)[8], const W64 &w) {   // pass 2 + its twiddles, in registers
-    dft8<+1>(z);
-    cplx p[8];
-    w64_powers(w, p);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) z[k1] = cmul(z[k1], p[k1]);
-}
-THFHE_FN void invh_tw(cplx (&z)[8], const W64 &w) {
-    dft8<-1>(z);
-    cplx p[8];
-    w64_powers(w, p);
-#pragma unroll
-    for (int j0 = 1; j0 < 8; j0++) z[j0] = cmul_conj(z[j0], p[j0]);
-}
-template <int PART>  // 0: real parts, 1: imaginary parts
-THFHE_FN void xh_put_c(int lane, const cplx (&z)[8], double *xr) {
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) xr[xs_c(k1, lane)] = PART ? z[k1].im : z[k1].re;
-}
-template <int PART>
-THFHE_FN void xh_get_d(int lane, cplx (&z)[8], const double *xr) {
-#pragma unroll
-    for (int j0 = 0; j0 < 8; j0++) (PART ? z[j0].im : z[j0].re) = xr[xs_d(j0, lane)];
-}
-template <int PART>
-THFHE_FN void xh_put_d(int lane, const cplx (&z)[8], double *xr) {
-#pragma unroll
-    for (int j0 = 0; j0 < 8; j0++) xr[xs_d(j0, lane)] = PART ? z[j0].im : z[j0].re;
-}
-template <int PART>
-THFHE_FN void xh_get_c(int lane, cplx (&z)[8], const double *xr) {
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) (PART ? z[k1].im : z[k1].re) = xr[xs_c(k1, lane)];
-}
-
 // ---- integer helpers ---------------------------------------------------------------------------------
 // coefficient q of X^a * p - p for p in LDS, a in [0, 2N)          (mul_by_monomial, J/rlwe.jl:130-131)
 THFHE_FN uint32_t rot_minus_self32(const int32_t *p, int q, int a2n, int N) {
@@ -638,13 +518,6 @@ THFHE_FN void cfma(cplx &s, cplx z, cplx b) {
     s.re = __builtin_fma(-z.im, b.im, s.re);
     s.im = __builtin_fma(z.im, b.re, s.im);
 }
-// s = z * b (first digit row of a CMux: saves zeroing the accumulating spectra)
-THFHE_FN void cmul_to(cplx &s, cplx z, cplx b) {
-    s.re = z.re * b.re;
-    s.im = z.re * b.im;
-    s.re = __builtin_fma(-z.im, b.im, s.re);
-    s.im = __builtin_fma(z.im, b.re, s.im);
-}
 // S[m] += z[m] * B[m*64 + lane], one slice at a time with the smallest register footprint: the ring kernels run at the 256-VGPR
 // limit, where this form (18 spilled registers) beats the batched-FMA form below (31+) by 4-20 % (measured)
 THFHE_FN void mac8_lean(int lane, cplx (&S)[8], const cplx (&z)[8], const cplx *B) {
@@ -687,25 +560,6 @@ THFHE_FN void acc_update16(int lane, int32_t *acc_poly, const cplx (&zlo)[8], co
         acc_poly[q + 512] = (int32_t)((uint32_t)acc_poly[q + 512] + vi);
     }
 }
-// acc_poly[q] += round(sgm lo) + (round(sgm hi) << 16) with sgm = sg for odd m: the 16 coefficients lam + 64 m (+ 512) of this lane
-THFHE_FN uint32_t round_lo32s(double x, double sg) {
-    double y = __builtin_fma(x, sg, 6755399441055744.0);
-    uint64_t b;
-    __builtin_memcpy(&b, &y, 8);
-    return (uint32_t)b;
-}
-THFHE_FN void acc_update16p(int lam, int32_t *acc_poly, const cplx (&zlo)[8], const cplx (&zhi)[8], double sg) {
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-        const int q = lam + 64 * m;
-        const double g = (m & 1) ? sg : 1.0;
-        uint32_t vr = (m & 1) ? round_lo32s(zlo[m].re, g) + (round_lo32s(zhi[m].re, g) << 16) : round_lo32(zlo[m].re) + (round_lo32(zhi[m].re) << 16);
-        uint32_t vi = (m & 1) ? round_lo32s(zlo[m].im, g) + (round_lo32s(zhi[m].im, g) << 16) : round_lo32(zlo[m].im) + (round_lo32(zhi[m].im) << 16);
-        acc_poly[q] = (int32_t)((uint32_t)acc_poly[q] + vr);
-        acc_poly[q + 512] = (int32_t)((uint32_t)acc_poly[q + 512] + vi);
-    }
-}
-
 // initial accumulator: acc = (0, X^{-barb} * (mu, ..., mu))            (J/bootstrap.jl:60-62,84)
 THFHE_FN void acc_init16(int lane, int32_t *acc_mask, int32_t *acc_body, int barb, int32_t mu) {
 #pragma unroll

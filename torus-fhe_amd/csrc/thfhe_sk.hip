@@ -53,29 +53,6 @@ __global__ __launch_bounds__(256) void sk_key_transform_kernel(const int32_t *__
         out[512 + m * 64 + lane] = cplx{zhi[m].re * (1.0 / 512), zhi[m].im * (1.0 / 512)};
     }
 }
-// the same for the spectrum layout of transform variant "p" (thfhe_lane.h): lane l owns the coefficient column lane_lam(l); the key is
-// transformed by the very code that transforms the digits, so lane order and the per-lane sign tau agree by construction
-__global__ __launch_bounds__(256) void sk_key_transform_p_kernel(const int32_t *__restrict__ polys, long npolys,
-                                                                  const cplx *__restrict__ tw, cplx *__restrict__ spec) {
-    __shared__ cplx sX[4][kXbufSlots];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lam = lane_lam(lane);
-    const long q = (long)blockIdx.x * 4 + wave;
-    if (q >= npolys) return;
-    const W64 w64{tw[512 + 1 * 8 + (lane & 7)]};
-    const LaneTw t = make_lane_tw_p(LaneRoots{tw[576 + 2 * lam], tw[576 + 2 * lam + 1]}, lane);
-    const LaneSg g = make_lane_sg(lane);
-    cplx zlo[8], zhi[8];
-    key_limbs_to_z(lam, polys + q * 1024, zlo, zhi);
-    cplx *xb = sX[wave];
-    wave_fft_fwd_p(lane, zlo, xb, t, w64, g);
-    wave_fft_fwd_p(lane, zhi, xb, t, w64, g);
-    cplx *out = spec + q * 1024;
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-        out[m * 64 + lane] = cplx{zlo[m].re * (1.0 / 512), zlo[m].im * (1.0 / 512)};
-        out[512 + m * 64 + lane] = cplx{zhi[m].re * (1.0 / 512), zhi[m].im * (1.0 / 512)};
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------
 // prologue: tmp = (0, cb) + cx * x + cy * y ; bara = decode_message(tmp.a, 2N) ; barb likewise
@@ -176,7 +153,7 @@ struct BRArgs {
 #ifndef THFHE_RING_NF
 #define THFHE_RING_NF 16
 #endif
-template <int L, int V = 1, int NF = THFHE_RING_NF>
+template <int L, int V = 1>
 __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) {
     __shared__ __attribute__((aligned(4096))) int32_t sAcc[8][2048];   // rotated_digits_z ORs byte offsets into the polynomial base
     __shared__ cplx sX[8][kXbufSlots];
@@ -185,18 +162,15 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
-    constexpr bool P = (V & 8) != 0;   // transform variant "p": this lane owns the coefficient column lam, exchange with flipped naming
-    const int lam = P ? lane_lam(lane) : lane;
-    const LaneRoots roots{a.tw[576 + 2 * lam], a.tw[576 + 2 * lam + 1]};
-    const LaneTw tw = P ? make_lane_tw_p(roots, lane) : make_lane_tw(roots);
-    const LaneSg sg = make_lane_sg(lane);
+    const LaneRoots roots{a.tw[576 + 2 * lane], a.tw[576 + 2 * lane + 1]};
+    const LaneTw tw = make_lane_tw(roots);
     const long job = (long)blockIdx.x * 8 + wave;
     const bool has_job = job < a.jobs;
     int32_t *acc = sAcc[wave];
     cplx *xb = sX[wave];
     const int32_t *bara = a.bara + (has_job ? job : 0) * a.n_pad;
     const int Bgbit = a.Bgbit;
-    if (has_job) acc_init16(lam, acc, acc + 1024, a.barb[job], a.mu);
+    if (has_job) acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
 
     const long total_chunks = (long)a.n * ROWS * 4;
     const cplx *gsrc = a.bk + wave * 64 + lane;
@@ -219,20 +193,17 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
     STAMP_DECL;
 
     for (int i = 0; i < a.n; i++) {
-        const int ai = __builtin_amdgcn_readfirstlane(bara[i]);   // wave-uniform by construction; tells the compiler so (the asm below wants an SGPR)
+        const int ai = bara[i];
         const bool active = has_job && ai != 0;
         const int a2n = ai & 2047;
         cplx S[2][2][8];
-        constexpr bool ZI = (V & 16) == 0;   // zero-initialised spectra; V & 16: the first digit row multiplies instead of accumulating
-        if (ZI) {
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+        for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int h = 0; h < 2; h++)
+            for (int h = 0; h < 2; h++)
 #pragma unroll
-                    for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
-        }
-        
+                for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
+        constexpr int NF = THFHE_RING_NF;   // rotated fields kept across the levels of a polynomial (register budget)
         uint32_t fld[NF];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
@@ -241,12 +212,10 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
                 // index / sign / subtraction once per accumulator polynomial, then one signed bit-field extract + one conversion per level
                 int a2n_r = a2n;
                 asm volatile("" : "+s"(a2n_r));  // opaque per row: the rotated LDS addresses are recomputed, not kept alive
-                if (r % L == 0) rotated_fields_keep<NF>(lam, acc + (r / L) * 1024, a2n_r, L, Bgbit, fld);
+                if (r % L == 0) rotated_fields_keep<NF>(lane, acc + (r / L) * 1024, a2n_r, L, Bgbit, fld);
                 asm volatile("" : "+s"(a2n_r));
-                mixed_digits_z<NF>(lam, acc + (r / L) * 1024, a2n_r, (r % L) + 1, L, Bgbit, fld, z);
-                if (P) wave_fft_fwd_p(lane, z, xb, tw, w64, sg);
-                else if (V & 4) wave_fft_fwd_qh(lane, z, reinterpret_cast<double *>(xb), tw, w64);
-                else if (V & 1) wave_fft_fwd_q(lane, z, xb, tw, w64); else wave_fft_fwd_r(lane, z, xb, roots, w64);
+                mixed_digits_z<NF>(lane, acc + (r / L) * 1024, a2n_r, (r % L) + 1, L, Bgbit, fld, z);
+                if (V & 1) wave_fft_fwd_q(lane, z, xb, tw, w64); else wave_fft_fwd_r(lane, z, xb, roots, w64);
             }
             STAMP(0);
             cplx bA[4], bB[4];
@@ -261,18 +230,12 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
                     for (int m = 0; m < 4; m++) bA[m] = B[m * 64 + lane];
                     if (c4 > 0) {
 #pragma unroll
-                        for (int m = 0; m < 4; m++) {
-                            if (!ZI && r == 0) cmul_to(S[(c4 - 1) >> 1][(c4 - 1) & 1][4 + m], z[4 + m], bB[m]);
-                            else cfma(S[(c4 - 1) >> 1][(c4 - 1) & 1][4 + m], z[4 + m], bB[m]);
-                        }
+                        for (int m = 0; m < 4; m++) cfma(S[(c4 - 1) >> 1][(c4 - 1) & 1][4 + m], z[4 + m], bB[m]);
                     }
 #pragma unroll
                     for (int m = 0; m < 4; m++) bB[m] = B[(4 + m) * 64 + lane];
 #pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        if (!ZI && r == 0) cmul_to(S[c4 >> 1][c4 & 1][m], z[m], bA[m]);
-                        else cfma(S[c4 >> 1][c4 & 1][m], z[m], bA[m]);
-                    }
+                    for (int m = 0; m < 4; m++) cfma(S[c4 >> 1][c4 & 1][m], z[m], bA[m]);
                 }
                 slot_use = slot_use == 2 ? 0 : slot_use + 1;
                 STAMP(2);
@@ -282,10 +245,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
             STAMP(1);
             if (active) {
 #pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    if (!ZI && r == 0) cmul_to(S[1][1][4 + m], z[4 + m], bB[m]);
-                    else cfma(S[1][1][4 + m], z[4 + m], bB[m]);
-                }
+                for (int m = 0; m < 4; m++) cfma(S[1][1][4 + m], z[4 + m], bB[m]);
             }
             STAMP(2);
         }
@@ -293,147 +253,20 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
             wave_sync();
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                if (P) {
-                    wave_fft_inv_p(lane, S[c][0], xb, tw, w64, sg);
-                    wave_fft_inv_p(lane, S[c][1], xb, tw, w64, sg);
-                } else if (V & 4) {
-                    wave_fft_inv_qh(lane, S[c][0], reinterpret_cast<double *>(xb), tw, w64);
-                    wave_fft_inv_qh(lane, S[c][1], reinterpret_cast<double *>(xb), tw, w64);
-                } else if ((V & 1) && !(V & 2)) {
+                if ((V & 1) && !(V & 2)) {
                     wave_fft_inv_q(lane, S[c][0], xb, tw, w64);
                     wave_fft_inv_q(lane, S[c][1], xb, tw, w64);
                 } else {
                     wave_fft_inv_r(lane, S[c][0], xb, roots, w64);
                     wave_fft_inv_r(lane, S[c][1], xb, roots, w64);
                 }
-                if (P) acc_update16p(lam, acc + c * 1024, S[c][0], S[c][1], sg.sg());
-                else acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
+                acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
             }
             wave_sync();
         }
         STAMP(3);
     }
     STAMP_FLUSH(blockIdx.x, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (has_job) extract16(lam, acc, acc + 1024, a.out + job * 1025);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// blind rotate + extract, throughput kernel, fourth generation ("ring6").  Same work per wave as sk_blind_rotate_ring_kernel; what changes
-// is the hand-off.  That kernel met at 30 workgroup barriers per CMux (five per digit row, 32 FMAs per wave between two of them): after
-// every barrier all eight waves restart in lock step with a ring read, and the SIMD idles for the round trip (SQ_WAIT_ANY 30 % of the
-// wave cycles in profiles/r02_summary.md).  Here the LDS transposes go through 4.5 KiB buffers of doubles (variant "qh", thfhe_lane.h:
-// real parts, then imaginary parts, same LDS cycles), which frees 36 KiB:
-//     8 x (accumulator 8 KiB + transpose buffer 4.5 KiB) | key ring 6 x 8 KiB                                           = 151 552 B
-// and the ring is handed over in PAIRS of chunks (one column of a row: its low and its high limb): 12 barriers per CMux, 64 FMAs per wave
-// in one stretch between two of them, the slices of the second chunk requested under the FMAs of the first.  Chunk q lives in slot
-// q mod 6.  Hand-off of pair p (chunks 2p, 2p+1): every wave waits for its own two slices (s_waitcnt vmcnt(2): chunks 2p+2, 2p+3 may
-// still be in flight), then s_barrier -- after it the pair is complete and everybody has finished reading pair p-1, whose two slots are
-// refilled at once with chunks 2p+4, 2p+5 (four chunks = a whole row ahead of the reader).
-// ------------------------------------------------------------------------------------------------------
-template <int L, int NF = THFHE_RING_NF>
-__global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring6_kernel(BRArgs a) {
-    __shared__ __attribute__((aligned(4096))) int32_t sAcc[8][2048];
-    __shared__ double sXh[8][kXhalfSlots];
-    __shared__ cplx sRing[6][512];
-    constexpr int ROWS = 2 * L;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
-    const LaneRoots roots{a.tw[576 + 2 * lane], a.tw[576 + 2 * lane + 1]};
-    const LaneTw tw = make_lane_tw(roots);
-    const long job = (long)blockIdx.x * 8 + wave;
-    const bool has_job = job < a.jobs;
-    int32_t *acc = sAcc[wave];
-    double *xr = sXh[wave];
-    const int32_t *bara = a.bara + (has_job ? job : 0) * a.n_pad;
-    const int Bgbit = a.Bgbit;
-    if (has_job) acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
-
-    const long total_chunks = (long)a.n * ROWS * 4;
-    const cplx *gsrc = a.bk + wave * 64 + lane;
-    long q_issue = 0;
-    int slot_issue = 0;
-    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sRing[0][0] + (uint32_t)wave * 1024u;
-    auto issue = [&]() {
-        ring_dma(gsrc, (uint32_t)__builtin_amdgcn_readfirstlane((int)(ring_base + (uint32_t)slot_issue * 8192u)));
-        if (q_issue + 1 < total_chunks) {   // past the end the last chunk is fetched again: every wave keeps the same DMA count
-            gsrc += 512;
-            q_issue++;
-        }
-        slot_issue = slot_issue == 5 ? 0 : slot_issue + 1;
-    };
-    __syncthreads();
-    issue();
-    issue();
-    issue();
-    issue();
-    int slot_use = 0;
-
-    for (int i = 0; i < a.n; i++) {
-        const int ai = __builtin_amdgcn_readfirstlane(bara[i]);
-        const bool active = has_job && ai != 0;
-        const int a2n = ai & 2047;
-        cplx S[2][2][8];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
-        
-        uint32_t fld[NF];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            cplx z[8];
-            if (active) {
-                int a2n_r = a2n;
-                asm volatile("" : "+s"(a2n_r));
-                if (r % L == 0) rotated_fields_keep<NF>(lane, acc + (r / L) * 1024, a2n_r, L, Bgbit, fld);
-                asm volatile("" : "+s"(a2n_r));
-                mixed_digits_z<NF>(lane, acc + (r / L) * 1024, a2n_r, (r % L) + 1, L, Bgbit, fld, z);
-                wave_fft_fwd_qh(lane, z, xr, tw, w64);
-            }
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                ring_barrier<2>();   // pair (r, c) complete; pair before it read by all
-                issue();
-                issue();
-                const cplx *B0 = &sRing[slot_use][0];
-                const cplx *B1 = &sRing[slot_use == 5 ? 0 : slot_use + 1][0];
-                if (active) {
-                    cplx bA[4], bB[4];
-#pragma unroll
-                    for (int m = 0; m < 4; m++) bA[m] = B0[m * 64 + lane];
-#pragma unroll
-                    for (int m = 0; m < 4; m++) bB[m] = B0[(4 + m) * 64 + lane];
-#pragma unroll
-                    for (int m = 0; m < 4; m++) cfma(S[c][0][m], z[m], bA[m]);
-#pragma unroll
-                    for (int m = 0; m < 4; m++) bA[m] = B1[m * 64 + lane];
-#pragma unroll
-                    for (int m = 0; m < 4; m++) cfma(S[c][0][4 + m], z[4 + m], bB[m]);
-#pragma unroll
-                    for (int m = 0; m < 4; m++) bB[m] = B1[(4 + m) * 64 + lane];
-#pragma unroll
-                    for (int m = 0; m < 4; m++) cfma(S[c][1][m], z[m], bA[m]);
-#pragma unroll
-                    for (int m = 0; m < 4; m++) cfma(S[c][1][4 + m], z[4 + m], bB[m]);
-                }
-                slot_use = slot_use >= 4 ? slot_use - 4 : slot_use + 2;
-            }
-        }
-        if (active) {
-            wave_sync();
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                wave_fft_inv_qh(lane, S[c][0], xr, tw, w64);
-                wave_fft_inv_qh(lane, S[c][1], xr, tw, w64);
-                acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
-            }
-            wave_sync();
-        }
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (has_job) extract16(lane, acc, acc + 1024, a.out + job * 1025);
 }
@@ -460,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring6_kernel(BRArgs a)
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void pin() { asm volatile("" ::: "memory"); }  // memory operations do not move across this point
 
-template <int L, int PACE = 1, bool P = false>
+template <int L, int PACE = 1>
 __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) {
     constexpr int ROWS = 2 * L;
     __shared__ __attribute__((aligned(4096))) int32_t sAcc[2048];
@@ -469,14 +302,11 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
-    const int lam = P ? lane_lam(lane) : lane;   // transform variant "p": coefficient column of this lane
-    const LaneRoots roots{a.tw[576 + 2 * lam], a.tw[576 + 2 * lam + 1]};
-    const LaneTw twp = P ? make_lane_tw_p(roots, lane) : make_lane_tw(roots);
-    const LaneSg sg = make_lane_sg(lane);
+    const LaneRoots roots{a.tw[576 + 2 * lane], a.tw[576 + 2 * lane + 1]};
     const long job = blockIdx.x;
     const int32_t *bara = a.bara + job * a.n_pad;
     const int Bgbit = a.Bgbit;
-    if (wave == 0) acc_init16(lam, sAcc, sAcc + 1024, a.barb[job], a.mu);
+    if (wave == 0) acc_init16(lane, sAcc, sAcc + 1024, a.barb[job], a.mu);
     const int c = (wave >> 1) & 1, h = wave & 1, half = wave >> 2, r0 = half * L;  // role in M: rows r0 .. r0+L-1 of (column c, limb h)
     unsigned int *ap = reinterpret_cast<unsigned int *>(sAcc) + c * 1024;
     cplx *xb = sX[wave];
@@ -498,8 +328,8 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
         // ---- F ----
         if (wave < ROWS) {
             cplx z[8];
-            rotated_digits_z(lam, sAcc + (wave / L) * 1024, a2n, (wave % L) + 1, L, Bgbit, z);
-            if (P) wave_fft_fwd_p(lane, z, xb, twp, w64, sg); else wave_fft_fwd_q(lane, z, xb, roots, w64);
+            rotated_digits_z(lane, sAcc + (wave / L) * 1024, a2n, (wave % L) + 1, L, Bgbit, z);
+            wave_fft_fwd_q(lane, z, xb, roots, w64);
 #pragma unroll
             for (int m = 0; m < 8; m++) sSpec[wave][m * 64 + lane] = z[m];
         }
@@ -559,24 +389,18 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
             pin();
             wave_sync();
             inv_seg2_ld(lane, S, xb);
-            if (P) dft8s<-1>(S, sg); else dft8<-1>(S);
+            dft8<-1>(S);
             pin();
             if (L > 2) load8(lane, B[L > 2 ? 2 : 0], a.bk + bk_spec_index(inl, r0 + 2, c, h, ROWS));
             if (L > 3) load8(lane, B[L > 3 ? 3 : 0], a.bk + bk_spec_index(inl, r0 + 3, c, h, ROWS));
             pin();
-            if (P) {
-                wave_transpose_hi3p(S);
-                invp_seg3(S, twp);
-            } else {
-                wave_transpose_hi3(S);
-                invq_seg3(S, roots);
-            }
+            wave_transpose_hi3(S);
+            invq_seg3(S, roots);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                const int q = lam + 64 * m;
-                const double gm = (P && (m & 1)) ? sg.sg() : 1.0;   // variant "p": the sign (-1)^m of the flipped lanes goes into the rounding step
-                atomicAdd(ap + q, round_lo32s(S[m].re, gm) << (16 * h));
-                atomicAdd(ap + q + 512, round_lo32s(S[m].im, gm) << (16 * h));
+                const int q = lane + 64 * m;
+                atomicAdd(ap + q, round_lo32(S[m].re) << (16 * h));
+                atomicAdd(ap + q + 512, round_lo32(S[m].im) << (16 * h));
             }
         }
         STAMP(3);
@@ -585,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
         i = inext;
     }
     STAMP_FLUSH(blockIdx.x, wave);
-    if (wave == 0) extract16(lam, sAcc, sAcc + 1024, a.out + job * 1025);
+    if (wave == 0) extract16(lane, sAcc, sAcc + 1024, a.out + job * 1025);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -804,7 +628,6 @@ struct thfhe_ctx {
     long ks_multi_min_gates = 1024;  // batches of at least this many gates use sk_keyswitch_multi_kernel (rows shared by the gates of a workgroup)
     int coop_max_jobs = 1024;  // batches up to this many rotations use the cooperative (latency) kernel (measured crossover ~1150)
     cplx *d_tw = nullptr;
-    int gen = 9;              // kernel generation (developer A/B through THFHE_RING_GEN at context creation; it fixes the spectrum layout of d_bk)
     // workspace
     size_t cap_jobs = 0;
     int n_pad = 0;
@@ -855,7 +678,7 @@ int ensure_stage(thfhe_ctx *c, size_t words) {
 }
 
 template <int L>
-void launch_br(const BRArgs &a, hipStream_t s, int coop_max, int gen) {
+void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
     // small batches: cooperative latency kernel (one workgroup per gate); large ones: LDS-ring kernel (eight gates per workgroup)
     if (a.jobs <= coop_max) {
 #ifdef THFHE_VARIANTS
@@ -864,8 +687,7 @@ void launch_br(const BRArgs &a, hipStream_t s, int coop_max, int gen) {
         if (pace == 2) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 2>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
         if (pace == 4) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 4>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
 #endif
-        if (gen >= 9) hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 1, true>), dim3((unsigned)a.jobs), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 1>), dim3((unsigned)a.jobs), dim3(512), 0, s, a);
+        hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 1>), dim3((unsigned)a.jobs), dim3(512), 0, s, a);
         return;
     }
     const dim3 grid((unsigned)((a.jobs + 7) / 8)), block(512);
@@ -874,18 +696,7 @@ void launch_br(const BRArgs &a, hipStream_t s, int coop_max, int gen) {
     if (variant == 8) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 0>), grid, block, 0, s, a); return; }
     if (variant == 3) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 3>), grid, block, 0, s, a); return; }   // forward in registers, inverse through the LDS
 #endif
-    if (gen == 9) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 9>), grid, block, 0, s, a); return; }   // transform variant "p"
-    if (gen == 10) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 9, 8>), grid, block, 0, s, a); return; }
-    if (gen == 11) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 9, 5>), grid, block, 0, s, a); return; }
-    if (gen == 13) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 25>), grid, block, 0, s, a); return; }       // p + multiply-first-row
-    if (gen == 14) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 25, 8>), grid, block, 0, s, a); return; }
-    if (gen == 2) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 17>), grid, block, 0, s, a); return; }        // third generation + multiply-first-row
-    if (gen == 12) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 9, 12>), grid, block, 0, s, a); return; }
-    if (gen == 3) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 1>), grid, block, 0, s, a); return; }
-    if (gen == 5) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 5>), grid, block, 0, s, a); return; }   // third generation with the half-buffer transposes
-    if (gen == 6) { hipLaunchKernelGGL((sk_blind_rotate_ring6_kernel<L, 8>), grid, block, 0, s, a); return; }
-    if (gen == 7) { hipLaunchKernelGGL((sk_blind_rotate_ring6_kernel<L, 5>), grid, block, 0, s, a); return; }
-    hipLaunchKernelGGL((sk_blind_rotate_ring6_kernel<L>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 1>), grid, block, 0, s, a);
 }
 
 // rotations (prologue + blind rotate) of `jobs` = gates * rot_per_gate jobs into c->d_u
@@ -902,10 +713,10 @@ int enqueue_rotations(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[1], c->stream));
     BRArgs a{c->d_bk, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)jobs, n, c->n_pad, c->p.Bgbit, mu};
     switch (c->p.l) {
-    case 1: launch_br<1>(a, c->stream, c->coop_max_jobs, c->gen); break;
-    case 2: launch_br<2>(a, c->stream, c->coop_max_jobs, c->gen); break;
-    case 3: launch_br<3>(a, c->stream, c->coop_max_jobs, c->gen); break;
-    case 4: launch_br<4>(a, c->stream, c->coop_max_jobs, c->gen); break;
+    case 1: launch_br<1>(a, c->stream, c->coop_max_jobs); break;
+    case 2: launch_br<2>(a, c->stream, c->coop_max_jobs); break;
+    case 3: launch_br<3>(a, c->stream, c->coop_max_jobs); break;
+    case 4: launch_br<4>(a, c->stream, c->coop_max_jobs); break;
     default: return thfhe_fail(THFHE_E_UNSUPPORTED, "decomposition length l must be 1..4");
     }
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[2], c->stream));
@@ -1026,9 +837,7 @@ int thfhe_ctx_create(const thfhe_params *p, const int32_t *bk_coeff, const int32
     CK(hipMalloc(&d_coeff, (size_t)npolys * 1024 * sizeof(int32_t)));
     CK(hipMemcpyAsync(d_coeff, bk_coeff, (size_t)npolys * 1024 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     CK(hipMalloc(&c->d_bk, (size_t)npolys * 1024 * sizeof(cplx)));
-    if (const char *g = std::getenv("THFHE_RING_GEN")) c->gen = std::atoi(g);   // developer A/B; gen 9 (default): transform variant "p" and its spectrum layout
-    if (c->gen >= 9) hipLaunchKernelGGL(sk_key_transform_p_kernel, dim3((unsigned)((npolys + 3) / 4)), dim3(256), 0, c->stream, d_coeff, npolys, c->d_tw, c->d_bk);
-    else hipLaunchKernelGGL(sk_key_transform_kernel, dim3((unsigned)((npolys + 3) / 4)), dim3(256), 0, c->stream, d_coeff, npolys, c->d_tw, c->d_bk);
+    hipLaunchKernelGGL(sk_key_transform_kernel, dim3((unsigned)((npolys + 3) / 4)), dim3(256), 0, c->stream, d_coeff, npolys, c->d_tw, c->d_bk);
     CK(hipGetLastError());
     // key-switching key: pad rows to 640 words
     const long rows = (long)p->N * p->ks_t * ((1 << p->ks_basebit) - 1);
