@@ -261,8 +261,11 @@ def run_party(args, p, rank, world, barrier, max_reduce, backend, device):
     K = make_keys(args, p, True, device)
     first, last = topo["parties"]
     be = HipPartyBackend(p, (first, last), K.bk[first:last], K.ksk[first:last], device=device)
-    ev = PartyShardedEvaluator(p, be, group=group, pipeline_chunks=args.pipeline_chunks)
     B = args.batch * topo["group_size"]
+    # a pipeline of W ranks and C slices runs at C / (C + W - 1) of its steady rate, and a slice should still fill the chip (>= 256 gates:
+    # one workgroup per CU); with one rank per group there is no pipeline and the batch goes down in one launch
+    chunks = args.pipeline_chunks if args.pipeline_chunks > 0 else (1 if topo["group_size"] == 1 else max(1, B // 256))
+    ev = PartyShardedEvaluator(p, be, group=group, pipeline_chunks=chunks)
     gseed = 0x5EED0002 + 2 * topo["group"]      # every rank of a group sees the same ciphertexts (mk_internals.jl:23-37)
     rng = np.random.default_rng(gseed)
     bits_a, bits_b = rng.integers(0, 2, B), rng.integers(0, 2, B)
@@ -314,7 +317,7 @@ def run_party(args, p, rank, world, barrier, max_reduce, backend, device):
                                "ciphertexts resident in HBM",
                    "gates_per_group_per_step": B, "param_set": args.set,
                    "parallelism": f"party pipeline: {topo['groups']} group(s) x {topo['group_size']} rank(s), {last - first} parties per rank, "
-                                  f"{args.pipeline_chunks} pipeline chunks, {'RCCL' if backend == 'nccl' else backend} combine",
+                                  f"{chunks} pipeline chunk(s), {'RCCL' if backend == 'nccl' else backend} combine",
                    "mode": "party", "timing_backend": backend},
         "roofline": roof, "party_comm": comm, "bit_exact_decrypt_errors": errors,
     }, K, xa, xb, got
@@ -329,7 +332,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="gates per GPU per step")
     ap.add_argument("--mode", choices=("replicated", "party"), default="replicated",
                     help="replicated: every GPU holds all keys and runs its own batch; party: the parties' keys are dealt over the GPUs (3-gen sets)")
-    ap.add_argument("--pipeline-chunks", type=int, default=4, help="--mode party: slices of the batch in flight along the party pipeline")
+    ap.add_argument("--pipeline-chunks", type=int, default=0,
+                    help="--mode party: slices of a group's batch in flight along the party pipeline (0 = auto: one per 256 gates, 1 when a group is one rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-per-thread", type=int, default=None, help="gates per host thread in the CPU baseline sample (default 8; 1 for multi-key sets)")
     ap.add_argument("--dry-topology", action="store_true", help="rank start-up + rendezvous + barrier only (no GPU): rehearsal of --gpus N")

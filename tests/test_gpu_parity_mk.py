@@ -156,6 +156,29 @@ def test_mk_wide_base_16_plus_party_sets_bit_exact(O, name, n, parties):
     ck.close()
 
 
+@pytest.mark.parametrize("n,parties", [(10, 2), (3, 9)])
+def test_mk256_two_level_wide_base_gadget_bit_exact(O, n, parties):
+    # mktfhe_parameters_256party_3gen (J/mk_api.jl:304-310): N = 2048, l = 2, Bgbit = 18, ks 8/2.  Two levels of two 9-bit digit parts = eight row
+    # parts per CMux: more than the one-pass N = 2048 kernel holds in LDS, so the rotation goes through the batched kernel shared with the KMS scheme
+    # (thfhe_rot2k.h) on a key table in its layout, accumulators in global memory, digits taken from all 36 bits.  Gadget, ring and key-switch shape of
+    # the reference set; LWE dimension and party count reduced (9 parties: an odd count, more than one batch of chunks per party).
+    import thfhe
+    p = O.make_params("MK256", n=n, parties=parties)
+    s = O.SIGMAS["MK256"]
+    K = O.MKKeys(p, 87, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    ck = thfhe.MKCloudKey(thfhe.make_params(**p.as_dict()), K.bk, K.ksk, device=0)
+    assert ck.rotation_kernel_name(4) == "kms_tlev_rotate_kernel"
+    a = np.array([0, 0, 1, 1, 1]); b = np.array([0, 1, 0, 1, 1]); c = np.array([1, 0, 1, 0, 0])
+    ca, cb, cc = (K.encrypt_bits(v, s["lwe"], 60 + q) for q, v in enumerate((a, b, c)))
+    for op, args in ((O.NAND, (ca, cb)), (O.XOR, (ca, cb)), (O.AND3, (ca, cb, cc)), (O.MUX, (ca, cb, cc))):
+        assert np.array_equal(ck.gates(op, *args), orc.gates(op, *args)), op
+    assert np.array_equal(K.decrypt_bits(ck.gates(thfhe.NAND, ca, cb)), ~(a.astype(bool) & b.astype(bool)))
+    ref = np.stack([orc.keyswitch(orc.bootstrap_wo_keyswitch(r)) for r in ca[:2]])
+    assert np.array_equal(thfhe.mk_bootstrap_3gen(ck, thfhe.MU8_64, ca[:2]), ref)
+    ck.close()
+
+
 def test_mk16_full_size_bit_exact(O):
     # mktfhe_parameters_16party_3gen AS WRITTEN (J/mk_api.jl:214-220): P = 16, n = 590, N = 2048, l = 1, Bgbit = 26, ks 4/3 -- 9 440 sequential
     # CMuxes per gate through the three-part digit split and the shifted key-row copies of mk_expand_parts_kernel at the REAL party count

@@ -527,6 +527,20 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
     }
 }
 
+// the batched N = 2048 rotation (any number of row parts, two-part digits) shared with the KMS scheme
+#include "thfhe_rot2k.h"
+
+// initial accumulator of the batched path, in global memory: acc = (0, X^{-barb} * (mu, ..., mu))   (J/3gen_mk_internals.jl:91-92)
+__global__ __launch_bounds__(256) void mk_acc_init_2k_kernel(const int32_t *__restrict__ barb, int64_t mu, long jobs, int64_t *__restrict__ acc) {
+    const long job = blockIdx.x;
+    if (job >= jobs) return;
+    const int b = barb[job];
+    for (int q = threadIdx.x; q < 2048; q += 256) {
+        acc[job * 4096 + q] = 0;
+        acc[job * 4096 + 2048 + q] = (((q + b) & 4095) & 2048) ? (int64_t)(0ull - (uint64_t)mu) : mu;
+    }
+}
+
 __global__ __launch_bounds__(256) void mk_linear_kernel(const int32_t *__restrict__ x, const int32_t *__restrict__ y, int32_t *__restrict__ out,
                                                          size_t words, size_t rec, int mode) {
     // mode 0: copy, 1: negate, 2: (0, 1/8) + x + y   (the 3-gen MUX epilogue, J/3gen_mk_gates.jl:144-147)
@@ -562,6 +576,9 @@ struct thfhe_mk_ctx {
     cplx *d_tw = nullptr;
     int row_words = 0, w_pad = 0, words = 0, log2_2n = 11;
     long pair_threshold = 256;  // batches of more rotations than this run two gates per workgroup (mk_blind_rotate_pair_kernel)
+    bool batched = false;       // N = 2048 with l x digit parts > 3: thfhe_rot2k.h (row parts through the LDS in batches), key table in its layout
+    int64_t *d_acc = nullptr;   // batched path: accumulators in global memory, int64[jobs][2][2048]
+    size_t cap_acc = 0;
     int parts = 1, pw = 0;      // N = 2048 with a wide gadget base: digit parts and their width (MKBRArgs)
     size_t cap_jobs = 0;
     int32_t *d_bara = nullptr, *d_barb = nullptr, *d_u = nullptr, *d_tmp = nullptr;
@@ -605,6 +622,7 @@ int mk_ensure_stage(thfhe_mk_ctx *c, size_t words) {
     return THFHE_OK;
 }
 
+__global__ void mk_extract_kernel(const int64_t *__restrict__ acc, int32_t *__restrict__ out, long jobs, int N);
 int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a);
 
 // bootstrap (prologue + blind rotate + key switch) of `jobs` = gates * rot jobs; results to d_dst[jobs][P*n+1]
@@ -635,6 +653,27 @@ int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1,
 
 int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a) {
     const dim3 grid((unsigned)a.jobs), block(512);
+    if (c->batched) {
+        // accumulators in global memory: start (unless the caller hands one in), rotate by all P n key bits in place, then extract (unless the caller wants
+        // the accumulator itself)
+        int64_t *acc = a.acc_out;
+        if (!acc) {
+            if ((size_t)a.jobs > c->cap_acc) {
+                (void)hipFree(c->d_acc);
+                c->d_acc = nullptr;
+                c->cap_acc = 0;
+                THFHE_HIP(hipMalloc(&c->d_acc, (size_t)a.jobs * 4096 * sizeof(int64_t)));
+                c->cap_acc = (size_t)a.jobs;
+            }
+            acc = c->d_acc;
+        }
+        if (!a.acc_in) hipLaunchKernelGGL(mk_acc_init_2k_kernel, dim3((unsigned)a.jobs), dim3(256), 0, c->stream, a.barb, a.mu, a.jobs, acc);
+        KmsBRArgs k{c->d_bk, c->d_tw, a.bara, acc, a.acc_in ? a.acc_in : acc, a.jobs, a.pn, c->p.l, c->p.Bgbit, c->parts, c->pw, 1, 1, a.w_pad};
+        hipLaunchKernelGGL(kms_tlev_rotate_kernel, grid, block, 0, c->stream, k);
+        if (!a.acc_out) hipLaunchKernelGGL(mk_extract_kernel, grid, dim3(256), 0, c->stream, (const int64_t *)acc, a.out, a.jobs, 2048);
+        THFHE_HIP(hipGetLastError());
+        return THFHE_OK;
+    }
     if (c->p.N == 2048) {
         MKBRArgs b = a;
         b.parts = c->parts;
@@ -746,8 +785,12 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     // J/mk_api.jl:214-298); |sum| <= 2 l parts N 2^(pw-1) 2^15 <= 2^36.6 stays inside the N = 2048 exactness bound
     const int parts = p->Bgbit > 10 ? (p->Bgbit + 8) / 9 : 1;
     const int pw = parts > 1 ? (p->Bgbit + parts - 1) / parts : 0;
-    if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || p->l * p->Bgbit > 32 || (parts > 1 && (p->N != 2048 || p->l * parts > 3)))
-        return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 4, l*Bgbit <= 32, and Bgbit <= 10 (FP64 exactness bound) unless N = 2048 with l x ceil(Bgbit / 9) <= 3");
+    // l x parts <= 3: the one-pass N = 2048 kernel; more row parts (the 256-party set: l = 2, Bgbit = 18 -> 2 x 2 parts) go through the batched
+    // rotation of thfhe_rot2k.h, which knows one- and two-part digits.  Exactness: 2 l parts N 2^(part bits - 1) 2^15 <= 2^37 (section 4.3).
+    const bool batched = p->N == 2048 && p->l * parts > 3;
+    if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || (!batched && p->l * p->Bgbit > 32) || p->l * p->Bgbit > 64 || (parts > 1 && p->N != 2048) || (batched && parts > 2) ||
+        (batched && (double)(2 * p->l * parts) * 2048.0 * (double)(1 << ((parts > 1 ? pw : p->Bgbit) - 1)) * 32768.0 > 137438953472.0))
+        return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 4, l*Bgbit <= 32 (64 on the batched path), and Bgbit <= 10 (FP64 exactness bound) unless N = 2048 with l x ceil(Bgbit / 9) <= 3 or two-part digits");
     if (p->n < 1 || p->n > 767) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= n <= 767");
     if (p->ks_t < 1 || p->ks_basebit < 1 || p->ks_t * p->ks_basebit > 31) return thfhe_fail(THFHE_E_INVALID, "bad key-switch parameters");
     int ndev = 0;
@@ -764,6 +807,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     c->log2_2n = ilog2(2 * p->N);
     c->parts = parts;
     c->pw = pw;
+    c->batched = batched;
     int64_t *d_coeff = nullptr, *d_exp = nullptr;  // upload staging, freed on every path
     int32_t *d_raw = nullptr;
     auto fail = [&](int code) {
@@ -792,6 +836,36 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     make_lane_roots_1024(tw.data() + 1088);
     CK(hipMalloc(&c->d_tw, tw.size() * sizeof(cplx)));
     CK(hipMemcpyAsync(c->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
+    if (batched) {
+        // key table of thfhe_rot2k.h: [party * n + i][row part rp = (j l + level) parts + part][output o][limb][half][512]; row part (j, level,
+        // part) of output o is part_{mk_part_index(j, o)}[level] shifted left by part * pw bits (wrapping): d (*) K = d_lo (*) K + d_hi (*) (K << pw).
+        // Staged party by party (the 256-party set: 194 MB of coefficients per party, 185 GB of spectra in all).
+        const int RP = 2 * p->l * parts, N = 2048;
+        const size_t polys_per_party = (size_t)p->n * RP * 2;
+        CK(hipMalloc(&c->d_bk, (size_t)p->parties * polys_per_party * 4 * 1024 * sizeof(cplx)));
+        CK(hipMalloc(&d_coeff, polys_per_party * N * sizeof(int64_t)));
+        std::vector<int64_t> host(polys_per_party * N);
+        for (int q = 0; q < p->parties; q++) {
+            for (int i = 0; i < p->n; i++)
+                for (int j = 0; j < 2; j++)
+                    for (int lv = 0; lv < p->l; lv++)
+                        for (int part = 0; part < parts; part++)
+                            for (int o = 0; o < 2; o++) {
+                                const int64_t *src = bk_coeff + ((((size_t)q * p->n + i) * 4 + mk_part_index(j, o)) * p->l + lv) * N;
+                                const int rp = (j * p->l + lv) * parts + part;
+                                int64_t *dst = host.data() + (((size_t)i * RP + rp) * 2 + o) * N;
+                                const int sh = part * pw;
+                                for (int t = 0; t < N; t++) dst[t] = (int64_t)((uint64_t)src[t] << sh);
+                            }
+            CK(hipMemcpyAsync(d_coeff, host.data(), host.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(kms_key_transform_kernel, dim3((unsigned)((polys_per_party * 4 + 3) / 4)), dim3(256), 0, c->stream, d_coeff, (long)polys_per_party,
+                               c->d_tw, c->d_bk + (size_t)q * polys_per_party * 4 * 1024);
+            CK(hipGetLastError());
+            CK(hipStreamSynchronize(c->stream));   // `host` is reused for the next party
+        }
+        (void)hipFree(d_coeff);
+        d_coeff = nullptr;
+    } else {
     const long PN = (long)p->parties * p->n;
     const size_t coeff_words = (size_t)PN * 4 * p->l * p->N;
     CK(hipMalloc(&d_coeff, coeff_words * sizeof(int64_t)));
@@ -817,6 +891,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
         hipLaunchKernelGGL(mk_key_transform_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, c->stream, d_coeff, PN, p->l, c->d_tw, c->d_bk);
     }
     CK(hipGetLastError());
+    }
     const long rows = (long)p->parties * p->N * p->ks_t * ((1 << p->ks_basebit) - 1);
     CK(hipMalloc(&d_raw, (size_t)rows * (p->n + 1) * sizeof(int32_t)));
     CK(hipMemcpyAsync(d_raw, ksk, (size_t)rows * (p->n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -842,6 +917,7 @@ void thfhe_mk_ctx_destroy(thfhe_mk_ctx *c) {
     (void)hipFree(c->d_barb);
     (void)hipFree(c->d_u);
     (void)hipFree(c->d_tmp);
+    (void)hipFree(c->d_acc);
     for (auto &p : c->d_in) (void)hipFree(p);
     (void)hipFree(c->d_out);
     for (auto &e : c->ev)

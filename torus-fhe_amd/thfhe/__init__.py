@@ -51,6 +51,9 @@ PARAM_SETS = {
     "MK32": dict(n=620, N=2048, k=1, l=1, Bgbit=26, ks_t=4, ks_basebit=3, torus_bits=64, parties=32),
     "MK64": dict(n=650, N=2048, k=1, l=1, Bgbit=25, ks_t=4, ks_basebit=3, torus_bits=64, parties=64),
     "MK128": dict(n=670, N=2048, k=1, l=1, Bgbit=24, ks_t=5, ks_basebit=3, torus_bits=64, parties=128),
+    "MK32-fft": dict(n=680, N=2048, k=1, l=1, Bgbit=25, ks_t=5, ks_basebit=3, torus_bits=64, parties=32),   # mktfhe_parameters_32party_3gen_for_fft, mk_api.jl:255-261
+    # 256 parties: TWO levels with an 18-bit base (mk_api.jl:304-310) -> two 9-bit parts per level, eight row parts: the batched N = 2048 rotation
+    "MK256": dict(n=740, N=2048, k=1, l=2, Bgbit=18, ks_t=8, ks_basebit=2, torus_bits=64, parties=256),
     # CCS scheme (mk_bootstrap / mk_gate_nand): mktfhe_parameters_2party / _4party, mk_api.jl:4-10,56-62
     "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
     "CCS4": dict(n=560, N=1024, k=1, l=4, Bgbit=8, ks_t=8, ks_basebit=2, torus_bits=32, parties=4),
@@ -75,6 +78,8 @@ SIGMAS = {
     "MK32": dict(lwe=2.0**-16.12, bk=2.0**-62.0, ks=2.0**-16.12),
     "MK64": dict(lwe=2.0**-16.90, bk=2.0**-62.0, ks=2.0**-16.90),
     "MK128": dict(lwe=2.0**-17.42, bk=2.0**-62.0, ks=2.0**-17.42),
+    "MK32-fft": dict(lwe=2.0**-17.68, bk=2.0**-62.0, ks=2.0**-17.68),
+    "MK256": dict(lwe=2.0**-19.24, bk=2.0**-62.0, ks=2.0**-19.24),
     "CCS2": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS4": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS8": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
@@ -527,7 +532,8 @@ class MKCloudKey:
         """The blind-rotation kernel a batch of `rotations` is dispatched to (mk_launch_rotation in thfhe_mk.hip)."""
         p = self.params
         if p.N == 2048:
-            return f"mk_blind_rotate_coop2k_kernel<{p.l * (((p.Bgbit + 8) // 9) if p.Bgbit > 10 else 1)}>"
+            le = p.l * (((p.Bgbit + 8) // 9) if p.Bgbit > 10 else 1)
+            return "kms_tlev_rotate_kernel" if le > 3 else f"mk_blind_rotate_coop2k_kernel<{le}>"
         pair = p.l <= 3 and rotations > getattr(self, "_pair_threshold", 256)
         return f"mk_blind_rotate_{'pair' if pair else 'coop'}_kernel<{p.l}>"
 
