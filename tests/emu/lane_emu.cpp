@@ -100,42 +100,6 @@ struct WaveQ {  // third-generation ring kernel: as WaveR, first transpose in re
         for (int l = 0; l < 64; l++) invq_seg3(z[l], base.r[l]);
     }
 };
-struct WaveQH {  // duo kernel: as WaveQ, all twiddles resident, the LDS transpose through a 4.5 KiB buffer of doubles (real parts, then imaginary parts)
-    WaveR base;
-    double xr[kXhalfSlots];
-    LaneTw8 t[64];
-    W64P w[64];
-    WaveQH() {
-        for (int l = 0; l < 64; l++) {
-            t[l] = make_lane_tw8(base.r[l]);
-            w[l] = make_w64p(base.w[l]);
-        }
-    }
-    void fwd(cplx (*z)[8]) {
-        for (int l = 0; l < 64; l++) fwdq_seg1(z[l], t[l]);
-        lanes_transpose_hi3(z);
-        for (int l = 0; l < 64; l++) fwdh_tw(z[l], w[l]);
-        for (int l = 0; l < 64; l++) xh_put_c<0>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) xh_get_d<0>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) xh_put_c<1>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) {
-            xh_get_d<1>(l, z[l], xr);
-            dft8<+1>(z[l]);
-        }
-    }
-    void inv(cplx (*z)[8]) {
-        for (int l = 0; l < 64; l++) invh_tw(z[l], w[l]);
-        for (int l = 0; l < 64; l++) xh_put_d<0>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) xh_get_c<0>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) xh_put_d<1>(l, z[l], xr);
-        for (int l = 0; l < 64; l++) {
-            xh_get_c<1>(l, z[l], xr);
-            dft8<-1>(z[l]);
-        }
-        lanes_transpose_hi3(z);
-        for (int l = 0; l < 64; l++) invq_seg3(z[l], t[l]);
-    }
-};
 struct WaveQS {  // multi-key kernels: first transpose in registers, second through the XOR-swizzled 512-slot buffer (no room for padding)
     WaveR base;
     void fwd(cplx (*z)[8]) {
@@ -388,9 +352,6 @@ double emu_roots_variant_crosscheck(const int32_t *small, const int32_t *b, int3
 }
 double emu_regtranspose_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
     return variant_crosscheck<WaveQ>(small, b, out, dmax_out);
-}
-double emu_regtranspose_halfbuf_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
-    return variant_crosscheck<WaveQH>(small, b, out, dmax_out);
 }
 double emu_regtranspose_swizzled_variant_crosscheck(const int32_t *small, const int32_t *b, int32_t *out, double *dmax_out) {
     return variant_crosscheck<WaveQS>(small, b, out, dmax_out);

@@ -102,8 +102,7 @@ def test_swizzled_variant_matches_padded(E, O):
     assert np.array_equal(ref, got) and d < 1e-9
 
 
-@pytest.mark.parametrize("fn", ["emu_roots_variant_crosscheck", "emu_regtranspose_variant_crosscheck", "emu_regtranspose_swizzled_variant_crosscheck",
-                                "emu_regtranspose_halfbuf_variant_crosscheck"])
+@pytest.mark.parametrize("fn", ["emu_roots_variant_crosscheck", "emu_regtranspose_variant_crosscheck", "emu_regtranspose_swizzled_variant_crosscheck"])
 @pytest.mark.parametrize("case", ["random", "adversarial"])
 def test_roots_variant_exact_with_margin(E, O, case, fn):
     # second-generation ring kernel: pass-1 twiddles rebuilt from two per-lane roots (b * s^k0) instead of the T1 table.  The

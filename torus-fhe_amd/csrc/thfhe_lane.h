@@ -373,78 +373,6 @@ THFHE_FN void invq_seg3(cplx (&z)[8], const LaneTw &t) {
     for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
 }
 
-// ---- variant "qh" (duo kernel: two waves per job, registers to spare): as "q", with
-//   * ALL twiddles resident: the eight pass-1 products T1[k0][lane] = b s^k0 (LaneTw8) and the powers w^1 .. w^7 of the pass-2 root (W64P) are
-//     formed once per kernel -- variant "q" rebuilds ten of them in every transform (40 FP64 instructions) because the ring kernel has no
-//     registers for them;
-//   * the LDS transpose (register index <-> lane bits 0..2) through ONE 4.5 KiB buffer of doubles, real parts then imaginary parts: the same
-//     padded slot maps on 8-byte elements (conflict-free: 16 contiguous lanes of a ds_write cover the 32 banks once, 32 lanes of a ds_read
-//     the 64 banks once, at stride 9 slots = 18 dwords).  One wavefront's DS instructions execute in issue order, so the imaginary parts may
-//     be written right behind the reads of the real parts.  The buffer sits at the start of the wave's 8 KiB exchange area.
-constexpr int kXhalfSlots = 8 * 72;  // doubles (4608 B)
-struct LaneTw8 {
-    cplx t[8];
-};
-THFHE_FN LaneTw8 make_lane_tw8(const LaneRoots &r) {
-    LaneTw8 t;
-    t.t[0] = r.b;
-#pragma unroll
-    for (int k = 1; k < 8; k++) t.t[k] = cmul(t.t[k - 1], r.s);
-    return t;
-}
-struct W64P {
-    cplx p[8];  // p[k] = w^k, p[0] unused
-};
-THFHE_FN W64P make_w64p(const W64 &w) {
-    W64P q;
-    w64_powers(w, q.p);
-    return q;
-}
-THFHE_FN void fwdq_seg1(cplx (&z)[8], const LaneTw8 &t) {
-#pragma unroll
-    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
-    dft8<+1>(z);
-#pragma unroll
-    for (int k = 0; k < 8; k++) z[k] = cmul(z[k], t.t[k]);
-}
-THFHE_FN void invq_seg3(cplx (&z)[8], const LaneTw8 &t) {
-#pragma unroll
-    for (int k = 0; k < 8; k++) z[k] = cmul_conj(z[k], t.t[k]);
-    dft8<-1>(z);
-#pragma unroll
-    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
-}
-THFHE_FN void fwdh_tw(cplx (&z)[8], const W64P &w) {   // pass 2 + its twiddles, in registers
-    dft8<+1>(z);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) z[k1] = cmul(z[k1], w.p[k1]);
-}
-THFHE_FN void invh_tw(cplx (&z)[8], const W64P &w) {
-    dft8<-1>(z);
-#pragma unroll
-    for (int j0 = 1; j0 < 8; j0++) z[j0] = cmul_conj(z[j0], w.p[j0]);
-}
-template <int PART>  // 0: real parts, 1: imaginary parts
-THFHE_FN void xh_put_c(int lane, const cplx (&z)[8], double *xr) {
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) xr[xs_c(k1, lane)] = PART ? z[k1].im : z[k1].re;
-}
-template <int PART>
-THFHE_FN void xh_get_d(int lane, cplx (&z)[8], const double *xr) {
-#pragma unroll
-    for (int j0 = 0; j0 < 8; j0++) (PART ? z[j0].im : z[j0].re) = xr[xs_d(j0, lane)];
-}
-template <int PART>
-THFHE_FN void xh_put_d(int lane, const cplx (&z)[8], double *xr) {
-#pragma unroll
-    for (int j0 = 0; j0 < 8; j0++) xr[xs_d(j0, lane)] = PART ? z[j0].im : z[j0].re;
-}
-template <int PART>
-THFHE_FN void xh_get_c(int lane, cplx (&z)[8], const double *xr) {
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) (PART ? z[k1].im : z[k1].re) = xr[xs_c(k1, lane)];
-}
-
 // ---- integer helpers ---------------------------------------------------------------------------------
 // coefficient q of X^a * p - p for p in LDS, a in [0, 2N)          (mul_by_monomial, J/rlwe.jl:130-131)
 THFHE_FN uint32_t rot_minus_self32(const int32_t *p, int q, int a2n, int N) {
@@ -630,14 +558,6 @@ THFHE_FN void acc_update16(int lane, int32_t *acc_poly, const cplx (&zlo)[8], co
         uint32_t vi = round_lo32(zlo[m].im) + (round_lo32(zhi[m].im) << 16);
         acc_poly[q] = (int32_t)((uint32_t)acc_poly[q] + vr);
         acc_poly[q + 512] = (int32_t)((uint32_t)acc_poly[q + 512] + vi);
-    }
-}
-// one polynomial of the initial accumulator (duo kernel: a wave owns ONE accumulator polynomial): the mask is 0, the body X^{-barb} (mu, ..., mu)
-THFHE_FN void acc_init16_one(int lane, int32_t *poly, int body, int barb, int32_t mu) {
-#pragma unroll
-    for (int m = 0; m < 16; m++) {
-        const int q = lane + 64 * m, e = (q + barb) & 2047;
-        poly[q] = body ? ((e & 1024) ? (int32_t)(0u - (uint32_t)mu) : mu) : 0;
     }
 }
 // initial accumulator: acc = (0, X^{-barb} * (mu, ..., mu))            (J/bootstrap.jl:60-62,84)

@@ -413,125 +413,6 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// blind rotate + extract, throughput kernel, fourth generation ("duo"): TWO waves per job.
-//
-// The ring kernel keeps the four accumulating spectra of a job (two output columns x two limbs, 128 VGPRs) in ONE wave: at two waves per
-// SIMD that leaves no room for the twiddles (ten of them are rebuilt in every transform: 400 of its 3 460 FP64 instructions per CMux) and
-// costs 44 B per lane of scratch whose reloads wait on the key DMAs.  Here a job is a PAIR of waves and each wave owns one accumulator
-// polynomial c (0: mask, 1: body) end to end: it rotates and decomposes ITS polynomial (digit rows c l .. c l + l - 1), accumulates output
-// column c (two limb spectra, 64 VGPRs) over all 2l digit rows, inverse-transforms them and updates ITS polynomial.  The only thing the
-// two waves exchange is a digit spectrum per step: each publishes the row it has just transformed in its 8 KiB exchange area and reads the
-// partner's.  Every twiddle stays in registers, nothing spills, and the forward work is shared (l transforms per wave, none redundant).
-//   step s = 0 .. l-1:   T  rotate / decompose level s of the own polynomial, forward transform, publish the spectrum
-//                        B1 barrier: the step's eight key chunks have landed (vmcnt(0)) and the partner's spectrum is visible
-//                        M  S[h] += own spectrum x key(row c l + s, column c, limb h);  S[h] += partner's spectrum x key(row (1-c) l + s, c, h)
-//                        B2 barrier: ring and exchange areas are free; request the eight chunks of the next step (they land under its T)
-//   then two inverse transforms and the accumulator update of the own polynomial.
-// 2l + 0 barriers per CMux (the ring kernel: 10 l), 128 FMAs per wave in one stretch between B1 and B2, the key ring is exactly one step:
-// LDS = 4 x accumulator 8 KiB | 8 x exchange area 8 KiB (its first 4.5 KiB double as the transposes' buffer of doubles, variant "qh") |
-// ring 8 x 8 KiB = 160 KiB.  Four jobs per workgroup, one workgroup per CU.
-// ------------------------------------------------------------------------------------------------------
-template <int L>
-__global__ __launch_bounds__(512, 2) void sk_blind_rotate_duo_kernel(BRArgs a) {
-    __shared__ __attribute__((aligned(4096))) int32_t sAcc[4][2][1024];
-    __shared__ cplx sX[8][512];
-    __shared__ cplx sRing[8][512];
-    constexpr int ROWS = 2 * L;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int jslot = wave & 3, c = wave >> 2;   // job slot of the workgroup; accumulator polynomial = output column of this wave
-    const long job = (long)blockIdx.x * 4 + jslot;
-    const bool has_job = job < a.jobs;
-    int32_t *poly = sAcc[jslot][c];
-    cplx *xb = sX[wave];
-    const cplx *xp = sX[wave ^ 4];               // the partner's exchange area
-    double *xr = reinterpret_cast<double *>(xb);
-    const W64P w64 = make_w64p(W64{a.tw[512 + 1 * 8 + (lane & 7)]});
-    const LaneTw8 tw = make_lane_tw8(LaneRoots{a.tw[576 + 2 * lane], a.tw[576 + 2 * lane + 1]});
-    const int32_t *bara = a.bara + (has_job ? job : 0) * a.n_pad;
-    const int Bgbit = a.Bgbit;
-    if (has_job) acc_init16_one(lane, poly, c, a.barb[job], a.mu);
-
-    // key stream: slot k of step (i, s) holds chunk (row, column, limb) =
-    //   k = 0,1: (s, 0, h)   2,3: (l + s, 1, h)      <- multiplied by the OWN spectrum of the column-0 / column-1 waves
-    //   k = 4,5: (l + s, 0, h)   6,7: (s, 1, h)      <- multiplied by the PARTNER's spectrum
-    // so a wave of column c reads slots 2c + h and 4 + 2c + h.  Wave w brings slice w (1 KiB) of every chunk.
-    const cplx *kslice = a.bk + wave * 64 + lane;
-    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sRing[0][0] + (uint32_t)wave * 1024u;
-    auto issue_step = [&](int i, int s) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int cc = (k >> 1) & 1, h = k & 1;
-            const int r = (k < 4) == (cc == 0) ? s : L + s;
-            const size_t chunk = (((size_t)i * ROWS + r) * 2 + cc) * 2 + h;
-            ring_dma(kslice + chunk * 512, ring_base + (uint32_t)k * 8192u);
-        }
-    };
-    __syncthreads();
-    if (a.n > 0) issue_step(0, 0);
-
-    for (int i = 0; i < a.n; i++) {
-        const int ai = __builtin_amdgcn_readfirstlane(bara[i]);
-        const bool active = has_job && ai != 0;   // J/bootstrap.jl:40 -- the same for both waves of a job
-        const int a2n = ai & 2047;
-        cplx S[2][8];
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int m = 0; m < 8; m++) S[h][m] = cplx{0.0, 0.0};
-        uint32_t fld[16];
-        if (active) rotated_fields_keep<16>(lane, poly, a2n, L, Bgbit, fld);
-#pragma unroll
-        for (int s = 0; s < L; s++) {
-            cplx z[8];
-            if (active) {
-                mixed_digits_z<16>(lane, poly, a2n, s + 1, L, Bgbit, fld, z);
-                wave_fft_fwd_qh(lane, z, xr, tw, w64);
-                wave_sync();
-#pragma unroll
-                for (int m = 0; m < 8; m++) xb[m * 64 + lane] = z[m];
-            }
-            ring_barrier<0>();   // B1
-            if (active) {
-                cplx b0[8], b1[8];
-                load8(lane, b0, &sRing[2 * c][0]);
-                load8(lane, b1, &sRing[2 * c + 1][0]);
-                mac8r(S[0], z, b0);
-                load8(lane, b0, xp);                      // the partner's spectrum
-                mac8r(S[1], z, b1);
-                load8(lane, b1, &sRing[4 + 2 * c][0]);
-                mac8r(S[0], b0, b1);
-                load8(lane, b1, &sRing[4 + 2 * c + 1][0]);
-                mac8r(S[1], b0, b1);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B2
-            if (s + 1 < L) issue_step(i, s + 1);
-            else if (i + 1 < a.n) issue_step(i + 1, 0);
-        }
-        if (active) {
-            wave_sync();
-            wave_fft_inv_qh(lane, S[0], xr, tw, w64);
-            wave_fft_inv_qh(lane, S[1], xr, tw, w64);
-            acc_update16(lane, poly, S[0], S[1]);
-            wave_sync();
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (has_job) {   // rlwe_extract_sample (J/rlwe.jl:64-68): the mask wave writes a', the body wave b
-        int32_t *out = a.out + job * 1025;
-        if (c == 0) {
-#pragma unroll
-            for (int m = 0; m < 16; m++) {
-                const int q = lane + 64 * m;
-                out[q] = q == 0 ? poly[0] : (int32_t)(0u - (uint32_t)poly[1024 - q]);
-            }
-        } else if (lane == 0) {
-            out[1024] = poly[0];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // key switch.  One workgroup (4 waves) per gate; wave w takes input coordinates i = w (mod 4); every lane keeps
 // its 4*NX4 + 2*NX2 words of the padded output row in registers.  KSK rows are padded to 64*(4*NX4+2*NX2) words
 // (n = 630: 640 words = 2560 B, 16-B aligned): per row each lane issues NX4 16-byte and NX2 8-byte loads.
@@ -815,8 +696,6 @@ void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
     if (variant == 8) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 0>), grid, block, 0, s, a); return; }
     if (variant == 3) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 3>), grid, block, 0, s, a); return; }   // forward in registers, inverse through the LDS
 #endif
-    static const int gen = std::getenv("THFHE_RING_GEN") ? std::atoi(std::getenv("THFHE_RING_GEN")) : 0;   // developer A/B
-    if (gen == 20) { hipLaunchKernelGGL((sk_blind_rotate_duo_kernel<L>), dim3((unsigned)((a.jobs + 3) / 4)), block, 0, s, a); return; }
     hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 1>), grid, block, 0, s, a);
 }
 
