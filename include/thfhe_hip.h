@@ -251,6 +251,19 @@ int thfhe_kms_set_relin_keys(thfhe_kms_ctx *ctx, const int64_t *uni, const int64
 int thfhe_kms_lev_rlwe_mul(thfhe_kms_ctx *ctx, int party, int64_t *accum, const int64_t *lev, size_t count);
 int thfhe_kms_bootstrap(thfhe_kms_ctx *ctx, int64_t mu, const int32_t *x, int32_t *u, int32_t *out, size_t count, int fast_boot);
 int thfhe_kms_gates(thfhe_kms_ctx *ctx, int op, const int32_t *x, const int32_t *y, int32_t *out, size_t count, int fast_boot);
+/* Party-sharded KMS evaluation, device-resident (thfhe/kms_sharded.py): in mk_blind_rotate_new the per-party TLev rotations read nothing the
+ * relinearisation writes (new_mk_internals.jl:241-252), so ranks rotate disjoint blocks of parties, exchange the TLev accumulators once
+ * (RCCL all-gather on device tensors) and finish replicated.  All pointers are DEVICE pointers; op = opcode NAND .. ORYN or -1 (plain
+ * mk_bootstrap_new of x, mu = 1/8).
+ *   rotate_parties_dev : gate linear part + mod-switch, then mk_ith_blind_rotate for parties [first_party, first_party + n_parties)
+ *                        -> d_lev int64[n_parties][count][l_lev][2][N]                                   (returns after enqueueing)
+ *   finish_dev         : trivial accumulator, mk_lev_rlwe_mul for p = 0 .. P-1 with d_lev_all int64[P][count][l_lev][2][N], extraction,
+ *                        key switch -> d_out int32[count][P n + 1]                                        (returns after the digit-range check)
+ *   set_stream         : enqueue on the caller's HIP stream (NULL: the context's own)                                                    */
+int thfhe_kms_rotate_parties_dev(thfhe_kms_ctx *ctx, int op, const int32_t *d_x, const int32_t *d_y, int first_party, int n_parties, int64_t *d_lev,
+                                 size_t count);
+int thfhe_kms_finish_dev(thfhe_kms_ctx *ctx, int op, const int32_t *d_x, const int32_t *d_y, const int64_t *d_lev_all, int32_t *d_out, size_t count);
+int thfhe_kms_set_stream(thfhe_kms_ctx *ctx, void *hip_stream);
 
 #ifdef __cplusplus
 }

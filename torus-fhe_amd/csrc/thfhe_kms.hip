@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 
 #include <deque>
+#include <functional>
+#include <map>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -118,7 +120,8 @@ __global__ __launch_bounds__(256) void kms_rlwe_split_kernel(const int64_t *__re
 struct thfhe_kms_ctx {
     thfhe_kms_params p;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every call enqueues on
+    hipStream_t own_stream = nullptr;  // created with the context; `stream` differs only after thfhe_kms_set_stream
     cplx *d_tw = nullptr;
     cplx *d_bk = nullptr;       // [party][j][row part][o][h][half][512]
     int32_t *d_ksk = nullptr;
@@ -132,6 +135,14 @@ struct thfhe_kms_ctx {
     enum { W_X, W_Y, W_BARA, W_ACCUM, W_LEV, W_LEVSPEC, W_SMALL, W_EF, W_R, W_V, W_W01, W_TERMS, W_FIRST, W_INDEX, W_U, W_OUT, W_ACC1, W_COUNT };
     void *d_w[W_COUNT] = {};
     size_t cap_w[W_COUNT] = {};
+    // device-resident copies of the relinearisation index tables (terms / first of thfhe_pm_mac, decompose index lists, assemble positions):
+    // they depend only on (table kind, party, gates per call, route), so a steady stream of equally sized calls uploads them once
+    struct DevTab {
+        int32_t *d = nullptr;
+        size_t words = 0;
+    };
+    std::map<uint64_t, DevTab> tabs;
+    size_t tab_bytes = 0;
     std::mutex mu;
 };
 
@@ -193,7 +204,8 @@ int thfhe_kms_ctx_create(const thfhe_kms_params *p, const int64_t *gsw, const in
         hipError_t e_ = (expr);                                       \
         if (e_ != hipSuccess) return fail(thfhe_fail_hip(e_, #expr)); \
     } while (0)
-    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
     std::vector<cplx> tw(1088), unused(512);
     make_twiddles_2048(tw.data(), tw.data() + 512);
     make_twiddles_1024(unused.data(), tw.data() + 1024);
@@ -239,15 +251,16 @@ int thfhe_kms_ctx_create(const thfhe_kms_params *p, const int64_t *gsw, const in
 void thfhe_kms_ctx_destroy(thfhe_kms_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     (void)hipFree(c->d_tw);
     (void)hipFree(c->d_bk);
     (void)hipFree(c->d_ksk);
     for (auto &q : c->d_buf) (void)hipFree(q);
     for (auto &q : c->d_w) (void)hipFree(q);
+    for (auto &kv : c->tabs) (void)hipFree(kv.second.d);
     (void)hipFree(c->d_relin);
     (void)hipFree(c->d_flag);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -332,89 +345,112 @@ struct KmsTables {
         return keep.back();
     }
 };
-// out[j] = addend[j] + sum_terms sign * small[s] (*) spec[t], all operands device-resident; terms = (out, small, torus, sign), ascending in out
-int kms_mac(thfhe_kms_ctx *c, KmsTables &tabs, const int32_t *d_small, const cplx *d_spec, std::vector<int32_t> &terms, size_t n_out, const void *d_addend,
-            void *d_out) {
-    std::vector<int32_t> &first = tabs.add();
-    first.assign(n_out + 1, 0);
-    const size_t n_terms = terms.size() / 4;
-    for (size_t t = 0; t < n_terms; t++) first[terms[4 * t] + 1]++;
-    for (size_t j = 0; j < n_out; j++) first[j + 1] += first[j];
-    int rc = kms_w(c, thfhe_kms_ctx::W_TERMS, (n_terms ? n_terms : 1) * 16);
-    if (!rc) rc = kms_w(c, thfhe_kms_ctx::W_FIRST, (n_out + 1) * 4);
+// A table that depends only on its key (kind, party, gates, variant): built on the host by `build` and uploaded the first time, then served
+// from the device copy.  The cache is dropped wholesale when it passes 256 MB (the stream is drained first: queued kernels read it).
+constexpr uint64_t kms_key(int kind, int party, size_t G, int extra) {
+    return ((uint64_t)kind << 56) ^ ((uint64_t)(party & 0xFF) << 48) ^ ((uint64_t)(extra & 0xFF) << 40) ^ (uint64_t)(G & 0xFFFFFFFFFFull);
+}
+int kms_tab(thfhe_kms_ctx *c, KmsTables &tabs, uint64_t key, const std::function<void(std::vector<int32_t> &)> &build, const int32_t **d_out, size_t *words_out) {
+    auto it = c->tabs.find(key);
+    if (it == c->tabs.end()) {
+        std::vector<int32_t> &host = tabs.add();   // stays alive until the stream has been synchronised (asynchronous copy)
+        build(host);
+        if (c->tab_bytes + host.size() * 4 > (size_t)256 << 20) {
+            THFHE_HIP(hipStreamSynchronize(c->stream));
+            for (auto &kv : c->tabs) (void)hipFree(kv.second.d);
+            c->tabs.clear();
+            c->tab_bytes = 0;
+        }
+        thfhe_kms_ctx::DevTab t;
+        t.words = host.size();
+        THFHE_HIP(hipMalloc(&t.d, (t.words ? t.words : 1) * 4));
+        if (t.words) THFHE_HIP(hipMemcpyAsync(t.d, host.data(), t.words * 4, hipMemcpyHostToDevice, c->stream));
+        c->tab_bytes += t.words * 4;
+        it = c->tabs.emplace(key, t).first;
+    }
+    *d_out = it->second.d;
+    if (words_out) *words_out = it->second.words;
+    return THFHE_OK;
+}
+// out[j] = addend[j] + sum_terms sign * small[s] (*) spec[t], all operands device-resident; terms = (out, small, torus, sign), ascending in out.
+// The table [terms (4 words each) | first (n_out + 1 words)] comes from the cache under `key`; `build_terms` fills the term list on a miss.
+int kms_mac(thfhe_kms_ctx *c, KmsTables &tabs, uint64_t key, const int32_t *d_small, const cplx *d_spec, const std::function<void(std::vector<int32_t> &)> &build_terms,
+            size_t n_out, const void *d_addend, void *d_out) {
+    const int32_t *d_tab = nullptr;
+    size_t words = 0;
+    int rc = kms_tab(c, tabs, key, [&](std::vector<int32_t> &t) {
+        build_terms(t);
+        const size_t n_terms = t.size() / 4;
+        std::vector<int32_t> first(n_out + 1, 0);
+        for (size_t q = 0; q < n_terms; q++) first[t[4 * q] + 1]++;
+        for (size_t j = 0; j < n_out; j++) first[j + 1] += first[j];
+        t.insert(t.end(), first.begin(), first.end());
+    }, &d_tab, &words);
     if (rc) return rc;
-    if (n_terms) THFHE_HIP(hipMemcpyAsync(c->d_w[thfhe_kms_ctx::W_TERMS], terms.data(), n_terms * 16, hipMemcpyHostToDevice, c->stream));
-    THFHE_HIP(hipMemcpyAsync(c->d_w[thfhe_kms_ctx::W_FIRST], first.data(), (n_out + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    PMArgs a{d_small, d_spec, (const int32_t *)c->d_w[thfhe_kms_ctx::W_TERMS], (const int32_t *)c->d_w[thfhe_kms_ctx::W_FIRST], d_addend, d_out, c->d_tw,
-             (long)n_out, c->d_flag};
+    const size_t n_terms = (words - (n_out + 1)) / 4;
+    PMArgs a{d_small, d_spec, d_tab, d_tab + 4 * n_terms, d_addend, d_out, c->d_tw, (long)n_out, c->d_flag};
     hipLaunchKernelGGL((pm_mac_kernel<2048, 64>), dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, c->stream, a);
     THFHE_HIP(hipGetLastError());
     return THFHE_OK;
 }
-int kms_decompose(thfhe_kms_ctx *c, KmsTables &tabs, const int64_t *d_polys, const std::vector<int32_t> *index, size_t n, int l, int bg) {
+int kms_decompose(thfhe_kms_ctx *c, const int64_t *d_polys, const int32_t *d_index, size_t n, int l, int bg) {
     int rc = kms_w(c, thfhe_kms_ctx::W_SMALL, n * l * 2048 * sizeof(int32_t));
     if (rc) return rc;
-    const int32_t *d_index = nullptr;
-    if (index) {
-        rc = kms_w(c, thfhe_kms_ctx::W_INDEX, n * 4 + 64 * 4);
-        if (rc) return rc;
-        THFHE_HIP(hipMemcpyAsync(c->d_w[thfhe_kms_ctx::W_INDEX], index->data(), n * 4, hipMemcpyHostToDevice, c->stream));
-        d_index = (const int32_t *)c->d_w[thfhe_kms_ctx::W_INDEX];
-    }
     hipLaunchKernelGGL(kms_decompose_kernel, dim3((unsigned)n, 8), dim3(256), 0, c->stream, d_polys, d_index, (long)n, l, bg, (int32_t *)c->d_w[thfhe_kms_ctx::W_SMALL]);
     THFHE_HIP(hipGetLastError());
     return THFHE_OK;
 }
 // UniProduct_new on e, accum' = f - (u, u0 + w0, a_party += w1)   (J/new_mk_internals.jl:85-127, 204-206).  d_ef = e block [G][ns][N] followed
-// by the f block; src[q] = which polynomial of the multi-key sample (0 .. P-1 masks, P body) row q is.
-int kms_relin_core(thfhe_kms_ctx *c, KmsTables &tabs, int party, size_t G, const std::vector<int> &src, int64_t *d_accum) {
+// by the f block; src[q] = which polynomial of the multi-key sample (0 .. P-1 masks, P body) row q is.  `route` (0: after a TLev product,
+// 1: the fast_boot start) keys the cached index tables: the same (party, G) has a different src in the two routes.
+int kms_relin_core(thfhe_kms_ctx *c, KmsTables &tabs, int party, size_t G, const std::vector<int> &src, int64_t *d_accum, int route) {
     typedef thfhe_kms_ctx K;
     const int P = c->p.parties, lu = c->p.l_uni, ns = (int)src.size();
-    const size_t N = 2048, spec_poly = 4 * 1024;   // complex elements per torus polynomial (4 limbs x 2 halves x 512)
+    const size_t N = 2048;
     const int64_t *d_e = (const int64_t *)c->d_w[K::W_EF], *d_f = d_e + G * ns * N;
     auto T_D = [&](int l) { return (party * 3 + 0) * lu + l; };
     auto T_F = [&](int w, int l) { return (party * 3 + 1 + w) * lu + l; };
     auto T_PK = [&](int i, int l) { return P * 3 * lu + i * lu + l; };
     auto T_A = [&](int l) { return P * 3 * lu + P * lu + l; };
-    (void)spec_poly;
-    int rc = kms_decompose(c, tabs, d_e, nullptr, G * ns, lu, c->p.bg_uni);
+    int rc = kms_decompose(c, d_e, nullptr, G * ns, lu, c->p.bg_uni);
     if (!rc) rc = kms_w(c, K::W_R, G * ns * N * 8);
     if (!rc) rc = kms_w(c, K::W_V, G * N * 8);
     if (!rc) rc = kms_w(c, K::W_W01, G * 2 * N * 8);
     if (rc) return rc;
     const int32_t *d_small = (const int32_t *)c->d_w[K::W_SMALL];
-    std::vector<int32_t> &t_u = tabs.add(), &t_v = tabs.add(), &t_w = tabs.add();
-    for (size_t g = 0; g < G; g++)
-        for (int q = 0; q < ns; q++)
-            for (int l = 0; l < lu; l++) {
-                const int32_t j = (int32_t)(g * ns + q);
-                t_u.insert(t_u.end(), {j, j * lu + l, T_D(l), -1});          // (f - u)_q = f_q - sum_l dec(e_q)[l] (*) d[l]
-            }
-    for (size_t g = 0; g < G; g++)
-        for (int q = 0; q < ns; q++)
-            for (int l = 0; l < lu; l++) {
-                const int32_t sm = (int32_t)((g * ns + q) * lu + l);
-                if (src[q] < P) t_v.insert(t_v.end(), {(int32_t)g, sm, T_PK(src[q], l), 1});   // v = sum_i <dec(e_i), pk_i> - <dec(e_b), crs>
-                else t_v.insert(t_v.end(), {(int32_t)g, sm, T_A(l), -1});
-            }
-    rc = kms_mac(c, tabs, d_small, c->d_relin, t_u, G * ns, d_f, c->d_w[K::W_R]);
-    if (!rc) rc = kms_mac(c, tabs, d_small, c->d_relin, t_v, G, nullptr, c->d_w[K::W_V]);
-    if (!rc) rc = kms_decompose(c, tabs, (const int64_t *)c->d_w[K::W_V], nullptr, G, lu, c->p.bg_uni);   // stream order: after the two products read W_SMALL
+    rc = kms_mac(c, tabs, kms_key(1, party, G, route), d_small, c->d_relin, [&](std::vector<int32_t> &t) {
+        for (size_t g = 0; g < G; g++)
+            for (int q = 0; q < ns; q++)
+                for (int l = 0; l < lu; l++) {
+                    const int32_t j = (int32_t)(g * ns + q);
+                    t.insert(t.end(), {j, j * lu + l, T_D(l), -1});          // (f - u)_q = f_q - sum_l dec(e_q)[l] (*) d[l]
+                }
+    }, G * ns, d_f, c->d_w[K::W_R]);
+    if (!rc) rc = kms_mac(c, tabs, kms_key(2, party, G, route), d_small, c->d_relin, [&](std::vector<int32_t> &t) {
+        for (size_t g = 0; g < G; g++)
+            for (int q = 0; q < ns; q++)
+                for (int l = 0; l < lu; l++) {
+                    const int32_t sm = (int32_t)((g * ns + q) * lu + l);
+                    if (src[q] < P) t.insert(t.end(), {(int32_t)g, sm, T_PK(src[q], l), 1});   // v = sum_i <dec(e_i), pk_i> - <dec(e_b), crs>
+                    else t.insert(t.end(), {(int32_t)g, sm, T_A(l), -1});
+                }
+    }, G, nullptr, c->d_w[K::W_V]);
+    if (!rc) rc = kms_decompose(c, (const int64_t *)c->d_w[K::W_V], nullptr, G, lu, c->p.bg_uni);   // stream order: after the two products read W_SMALL
     if (rc) return rc;
-    for (size_t g = 0; g < G; g++)
-        for (int w = 0; w < 2; w++)
-            for (int l = 0; l < lu; l++) t_w.insert(t_w.end(), {(int32_t)(g * 2 + w), (int32_t)(g * lu + l), T_F(w, l), 1});   // w0 = <dec(v), f0>, w1 = <dec(v), f1>
-    rc = kms_mac(c, tabs, (const int32_t *)c->d_w[K::W_SMALL], c->d_relin, t_w, G * 2, nullptr, c->d_w[K::W_W01]);
+    rc = kms_mac(c, tabs, kms_key(3, party, G, 0), (const int32_t *)c->d_w[K::W_SMALL], c->d_relin, [&](std::vector<int32_t> &t) {
+        for (size_t g = 0; g < G; g++)
+            for (int w = 0; w < 2; w++)
+                for (int l = 0; l < lu; l++) t.insert(t.end(), {(int32_t)(g * 2 + w), (int32_t)(g * lu + l), T_F(w, l), 1});   // w0 = <dec(v), f0>, w1 = <dec(v), f1>
+    }, G * 2, nullptr, c->d_w[K::W_W01]);
     if (rc) return rc;
-    std::vector<int32_t> &pos = tabs.add();
-    pos.assign(64, -1);
-    for (int q = 0; q < ns; q++) pos[src[q]] = q;
-    rc = kms_w(c, K::W_INDEX, (G * ns + 64) * 4);
+    const int32_t *d_pos = nullptr;
+    rc = kms_tab(c, tabs, kms_key(4, party, 0, route), [&](std::vector<int32_t> &pos) {
+        pos.assign(64, -1);
+        for (int q = 0; q < ns; q++) pos[src[q]] = q;
+    }, &d_pos, nullptr);
     if (rc) return rc;
-    int32_t *d_pos = (int32_t *)c->d_w[K::W_INDEX] + G * ns;   // behind the decompose index list of this step
-    THFHE_HIP(hipMemcpyAsync(d_pos, pos.data(), 64 * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(kms_assemble_kernel, dim3((unsigned)G, (unsigned)(P + 1)), dim3(256), 0, c->stream, (const int64_t *)c->d_w[K::W_R],
-                       (const int64_t *)c->d_w[K::W_W01], (const int32_t *)d_pos, ns, party, P, d_accum);
+                       (const int64_t *)c->d_w[K::W_W01], d_pos, ns, party, P, d_accum);
     THFHE_HIP(hipGetLastError());
     return THFHE_OK;
 }
@@ -427,24 +463,27 @@ int kms_lev_rlwe_mul_dev(thfhe_kms_ctx *c, KmsTables &tabs, int party, size_t G,
     for (int i = 0; i < party; i++) src.push_back(i);
     src.push_back(P);
     const int ns = (int)src.size();
-    std::vector<int32_t> &index = tabs.add(), &t1 = tabs.add();
-    for (size_t g = 0; g < G; g++)
-        for (int q = 0; q < ns; q++) index.push_back((int32_t)(g * (P + 1) + src[q]));
-    int rc = kms_decompose(c, tabs, d_accum, &index, G * ns, lv, c->p.bg_lev);
+    const int32_t *d_index = nullptr;
+    int rc = kms_tab(c, tabs, kms_key(5, party, G, 0), [&](std::vector<int32_t> &index) {
+        for (size_t g = 0; g < G; g++)
+            for (int q = 0; q < ns; q++) index.push_back((int32_t)(g * (P + 1) + src[q]));
+    }, &d_index, nullptr);
+    if (!rc) rc = kms_decompose(c, d_accum, d_index, G * ns, lv, c->p.bg_lev);
     if (!rc) rc = kms_w(c, K::W_LEVSPEC, G * lv * 2 * 4 * 1024 * sizeof(cplx));
     if (!rc) rc = kms_w(c, K::W_EF, 2 * G * ns * N * 8);
     if (rc) return rc;
     hipLaunchKernelGGL((pm_torus_transform_kernel<2048, 64>), dim3((unsigned)((G * lv * 2 * 4 + 3) / 4)), dim3(256), 0, c->stream, (const void *)d_lev,
                        (long)(G * lv * 2), c->d_tw, (cplx *)c->d_w[K::W_LEVSPEC]);
     THFHE_HIP(hipGetLastError());
-    for (int w = 0; w < 2; w++)   // e block (w = 0: masks of the TLev samples), then f block (w = 1: bodies)
-        for (size_t g = 0; g < G; g++)
-            for (int q = 0; q < ns; q++)
-                for (int s = 0; s < lv; s++)
-                    t1.insert(t1.end(), {(int32_t)((w * G + g) * ns + q), (int32_t)((g * ns + q) * lv + s), (int32_t)((g * lv + s) * 2 + w), 1});
-    rc = kms_mac(c, tabs, (const int32_t *)c->d_w[K::W_SMALL], (const cplx *)c->d_w[K::W_LEVSPEC], t1, 2 * G * ns, nullptr, c->d_w[K::W_EF]);
+    rc = kms_mac(c, tabs, kms_key(6, party, G, 0), (const int32_t *)c->d_w[K::W_SMALL], (const cplx *)c->d_w[K::W_LEVSPEC], [&](std::vector<int32_t> &t1) {
+        for (int w = 0; w < 2; w++)   // e block (w = 0: masks of the TLev samples), then f block (w = 1: bodies)
+            for (size_t g = 0; g < G; g++)
+                for (int q = 0; q < ns; q++)
+                    for (int s = 0; s < lv; s++)
+                        t1.insert(t1.end(), {(int32_t)((w * G + g) * ns + q), (int32_t)((g * ns + q) * lv + s), (int32_t)((g * lv + s) * 2 + w), 1});
+    }, 2 * G * ns, nullptr, c->d_w[K::W_EF]);
     if (rc) return rc;
-    return kms_relin_core(c, tabs, party, G, src, d_accum);
+    return kms_relin_core(c, tabs, party, G, src, d_accum, 0);
 }
 int kms_launch_rotation(thfhe_kms_ctx *c, int party, const int32_t *d_bara, int64_t *d_out, const int64_t *d_in, size_t gates, int l_lev) {
     KmsBRArgs a{c->d_bk + (size_t)party * c->party_stride, c->d_tw, d_bara, d_out, d_in, (long)(gates * l_lev),
@@ -494,7 +533,7 @@ int kms_bootstrap_body(thfhe_kms_ctx *c, KmsTables &tabs, int32_t cb, int32_t cx
         if (rc) return rc;
         hipLaunchKernelGGL(kms_rlwe_split_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, (const int64_t *)c->d_w[K::W_ACC1], (long)G, (int64_t *)c->d_w[K::W_EF]);
         THFHE_HIP(hipGetLastError());
-        rc = kms_relin_core(c, tabs, 0, G, std::vector<int>{P}, d_accum);
+        rc = kms_relin_core(c, tabs, 0, G, std::vector<int>{P}, d_accum, 1);
         if (rc) return rc;
         first = 1;
     }
@@ -590,14 +629,105 @@ int thfhe_kms_bootstrap(thfhe_kms_ctx *c, int64_t mu, const int32_t *x, int32_t 
     return kms_bootstrap_impl(c, 0, 1, 0, mu, x, nullptr, u, out, count, fast_boot);
 }
 
-int thfhe_kms_gates(thfhe_kms_ctx *c, int op, const int32_t *x, const int32_t *y, int32_t *out, size_t count, int fast_boot) {
-    // J/gates.jl:15-161, (constant, coefficient of x, coefficient of y) by opcode THFHE_NAND .. THFHE_ORYN; mu = 1/8 on Torus64
-    static const int32_t lin[10][3] = {{1 << 29, -1, -1}, {1 << 29, 1, 1}, {-(1 << 29), 1, 1}, {1 << 30, 2, 2}, {-(1 << 30), -2, -2},
+// J/gates.jl:15-161, (constant, coefficient of x, coefficient of y) by opcode THFHE_NAND .. THFHE_ORYN; mu = 1/8 on Torus64
+static const int32_t kKmsLin[10][3] = {{1 << 29, -1, -1}, {1 << 29, 1, 1}, {-(1 << 29), 1, 1}, {1 << 30, 2, 2}, {-(1 << 30), -2, -2},
                                        {-(1 << 29), -1, -1}, {-(1 << 29), -1, 1}, {-(1 << 29), 1, -1}, {1 << 29, -1, 1}, {1 << 29, 1, -1}};
+
+int thfhe_kms_gates(thfhe_kms_ctx *c, int op, const int32_t *x, const int32_t *y, int32_t *out, size_t count, int fast_boot) {
     if (!c || !x || !y || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
     if (op < 0 || op > 9) return thfhe_fail(THFHE_E_UNSUPPORTED, "the KMS scheme evaluates two-input bootstrapped gates (opcodes NAND .. ORYN)");
     if (count == 0) return THFHE_OK;
-    return kms_bootstrap_impl(c, lin[op][0], lin[op][1], lin[op][2], (int64_t)1 << 61, x, y, nullptr, out, count, fast_boot);
+    return kms_bootstrap_impl(c, kKmsLin[op][0], kKmsLin[op][1], kKmsLin[op][2], (int64_t)1 << 61, x, y, nullptr, out, count, fast_boot);
+}
+
+// ---- party-sharded mode, device-resident (thfhe/kms_sharded.py; SURVEY.md section 8e side note) -----------------------------------------------
+// The per-party TLev rotations read nothing the relinearisation writes (J/new_mk_internals.jl:241-252), so ranks rotate disjoint blocks of parties
+// and exchange the TLev accumulators once.  All pointers are DEVICE pointers; both calls enqueue on the context's stream and return at once
+// (rotate) / after the digit-range check (finish).  op = opcode NAND .. ORYN, or -1: plain mk_bootstrap_new of x with mu = 1/8.
+static int kms_lin_of(int op, int32_t &cb, int32_t &cx, int32_t &cy) {
+    if (op == -1) {
+        cb = 0, cx = 1, cy = 0;
+        return THFHE_OK;
+    }
+    if (op < 0 || op > 9) return thfhe_fail(THFHE_E_UNSUPPORTED, "the KMS scheme evaluates two-input bootstrapped gates (opcodes NAND .. ORYN)");
+    cb = kKmsLin[op][0], cx = kKmsLin[op][1], cy = kKmsLin[op][2];
+    return THFHE_OK;
+}
+// phase 1: gate linear part + mod-switch (J/numeric-functions.jl:70-73), then mk_ith_blind_rotate (J/new_mk_internals.jl:210-225) for parties
+// [first_party, first_party + n_parties) -> d_lev int64[n_parties][count][l_lev][2][N]
+int thfhe_kms_rotate_parties_dev(thfhe_kms_ctx *c, int op, const int32_t *d_x, const int32_t *d_y, int first_party, int n_parties, int64_t *d_lev, size_t count) {
+    typedef thfhe_kms_ctx K;
+    if (!c || !d_x || !d_lev) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    int32_t cb, cx, cy;
+    int rc = kms_lin_of(op, cb, cx, cy);
+    if (rc) return rc;
+    if (cy != 0 && !d_y) return thfhe_fail(THFHE_E_INVALID, "null operand");
+    if (first_party < 0 || n_parties < 0 || first_party + n_parties > c->p.parties) return thfhe_fail(THFHE_E_INVALID, "party block out of range");
+    if (count == 0 || n_parties == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> lock(c->mu);
+    THFHE_HIP(hipSetDevice(c->device));
+    const int P = c->p.parties, n = c->p.n, lv = c->p.l_lev;
+    const size_t G = count, N = 2048;
+    rc = kms_w(c, K::W_BARA, (size_t)P * G * n * 4);
+    if (!rc) rc = kms_w(c, K::W_ACCUM, G * (P + 1) * N * 8);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kms_prologue_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, d_x, cy != 0 ? d_y : nullptr, cb, cx, cy, n, P, (long)G, (int64_t)1 << 61,
+                       (int32_t *)c->d_w[K::W_BARA], (int64_t *)c->d_w[K::W_ACCUM]);
+    THFHE_HIP(hipGetLastError());
+    for (int q = 0; q < n_parties && !rc; q++)
+        rc = kms_launch_rotation(c, first_party + q, (const int32_t *)c->d_w[K::W_BARA] + (size_t)(first_party + q) * G * n, d_lev + (size_t)q * G * lv * 2 * N, nullptr, G, lv);
+    return rc;
+}
+// phase 2: accum = X^{-barb} mu (trivial), then mk_lev_rlwe_mul for p = 0 .. P-1 with d_lev_all int64[P][count][l_lev][2][N] (sequential by construction,
+// J/new_mk_internals.jl:276-283), mk_rlwe_extract_sample_64 + t64tot32, mk_keyswitch -> d_out int32[count][P n + 1]
+int thfhe_kms_finish_dev(thfhe_kms_ctx *c, int op, const int32_t *d_x, const int32_t *d_y, const int64_t *d_lev_all, int32_t *d_out, size_t count) {
+    typedef thfhe_kms_ctx K;
+    if (!c || !d_x || !d_lev_all || !d_out) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    int32_t cb, cx, cy;
+    int rc = kms_lin_of(op, cb, cx, cy);
+    if (rc) return rc;
+    if (cy != 0 && !d_y) return thfhe_fail(THFHE_E_INVALID, "null operand");
+    if (count == 0) return THFHE_OK;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!c->d_relin) return thfhe_fail(THFHE_E_INVALID, "thfhe_kms_set_relin_keys has not been called on this context");
+    THFHE_HIP(hipSetDevice(c->device));
+    KmsTables tabs;
+    const int P = c->p.parties, n = c->p.n, lv = c->p.l_lev;
+    const size_t G = count, N = 2048, words = (size_t)P * n + 1, uw = (size_t)P * N + 1;
+    auto body = [&]() -> int {
+        int r = kms_w(c, K::W_BARA, (size_t)P * G * n * 4);
+        if (!r) r = kms_w(c, K::W_ACCUM, G * (P + 1) * N * 8);
+        if (!r) r = kms_w(c, K::W_U, G * uw * 4);
+        if (r) return r;
+        THFHE_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+        int64_t *d_accum = (int64_t *)c->d_w[K::W_ACCUM];
+        hipLaunchKernelGGL(kms_prologue_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, d_x, cy != 0 ? d_y : nullptr, cb, cx, cy, n, P, (long)G, (int64_t)1 << 61,
+                           (int32_t *)c->d_w[K::W_BARA], d_accum);
+        THFHE_HIP(hipGetLastError());
+        for (int party = 0; party < P; party++) {
+            r = kms_lev_rlwe_mul_dev(c, tabs, party, G, d_accum, d_lev_all + (size_t)party * G * lv * 2 * N);
+            if (r) return r;
+        }
+        hipLaunchKernelGGL(kms_extract_kernel, dim3((unsigned)G, (unsigned)(P + 1)), dim3(256), 0, c->stream, (const int64_t *)d_accum, P, (int32_t *)c->d_w[K::W_U]);
+        THFHE_HIP(hipGetLastError());
+        THFHE_HIP(hipMemsetAsync(d_out, 0, G * words * 4, c->stream));
+        MKKSArgs k{c->d_ksk, (const int32_t *)c->d_w[K::W_U], d_out, (long)G, n, c->p.ks_t, c->p.ks_basebit, P, c->row_words, (int)N, (int)uw, (int)N};
+        const int nsplit = G <= 64 ? 8 : 2;
+        hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)G, (unsigned)P, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
+        THFHE_HIP(hipGetLastError());
+        return kms_finish(c);
+    };
+    rc = body();
+    if (rc) (void)hipStreamSynchronize(c->stream);
+    return rc;
+}
+// Enqueue every later call on the caller's HIP stream (the stream the caller's RCCL communicator orders with); NULL returns to the context's own stream.
+int thfhe_kms_set_stream(thfhe_kms_ctx *c, void *hip_stream) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    std::lock_guard<std::mutex> g(c->mu);
+    THFHE_HIP(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return THFHE_OK;
 }
 
 }  // extern "C"

@@ -164,6 +164,9 @@ SIGNATURES = {
     "thfhe_kms_lev_rlwe_mul": (C.c_int, [_vp, C.c_int, _i64p, _i64p, C.c_size_t]),
     "thfhe_kms_bootstrap": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, _i32p, C.c_size_t, C.c_int]),
     "thfhe_kms_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, C.c_size_t, C.c_int]),
+    "thfhe_kms_rotate_parties_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t]),
+    "thfhe_kms_finish_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "thfhe_kms_set_stream": (C.c_int, [_vp, _vp]),
     "thfhe_kms_keyswitch": (C.c_int, [_vp, _i32p, _i32p, C.c_size_t]),
     "thfhe_pm_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "thfhe_pm_ctx_destroy": (None, [_vp]),

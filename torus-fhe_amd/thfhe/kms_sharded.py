@@ -67,6 +67,66 @@ def gates_party_sharded(ck, op, x, y, rank=0, world=1, all_gather=None):
     return bootstrap_party_sharded(ck, t.astype(np.uint32).view(np.int32), MU8_64, rank, world, all_gather)
 
 
+class KmsShardedEvaluator:
+    """The same schedule with everything resident in HBM (C ABI: thfhe_kms_rotate_parties_dev / thfhe_kms_finish_dev): rank r rotates the block
+    of parties [r P/W, (r+1) P/W) into a device tensor, ONE all-gather of the TLev accumulators (RCCL on device tensors with backend "nccl";
+    staged through host memory with "gloo"), then every rank finishes replicated on its own GPU.  Nothing but the records the caller hands in
+    and gets back exists outside device memory; kernels, tensor plumbing and the collective are ordered on one side stream.
+    `ck` is a thfhe.kms.KMSCloudKey (all parties' keys: the relinearisation chain needs them; only the rotations are sharded)."""
+
+    def __init__(self, ck, device=0, group=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from . import _check, lib
+        if not torch.cuda.is_available():
+            raise ThfheError("KmsShardedEvaluator needs a HIP device (there is no CPU fallback)")
+        self.ck, self.group, self.torch, self.dist, self.C = ck, group, torch, dist, C
+        self.solo = group is None and not (dist.is_available() and dist.is_initialized())
+        self.rank, self.world = (0, 1) if self.solo else (dist.get_rank(group), dist.get_world_size(group))
+        P = ck.params.parties
+        if P % self.world:
+            raise ValueError(f"the rank count must divide the parties (world {self.world}, parties {P})")
+        self.per_rank = P // self.world
+        self.device = torch.device("cuda", device)
+        self.stream = torch.cuda.Stream(self.device)
+        _check(lib().thfhe_kms_set_stream(ck.h, C.c_void_p(self.stream.cuda_stream)))
+        self.host_staged = (not self.solo) and dist.get_backend(group) != "nccl"
+
+    def close(self):
+        from . import _check, lib
+        if getattr(self.ck, "h", None):
+            _check(lib().thfhe_kms_set_stream(self.ck.h, None))
+
+    def gates(self, op, x, y=None):
+        """mk_gate_nand_new (op = NAND) and the other two-input gates; op = -1: mk_bootstrap_new of x.  x, y: int32 device tensors
+        [count][P n + 1] (the same on every rank); returns the output records as a device tensor on every rank."""
+        from . import _check, lib
+        torch, dist, C, p = self.torch, self.dist, self.C, self.ck.params
+        G, m = x.shape[0], self.per_rank
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            lev_mine = torch.empty((m, G, p.l_lev, 2, p.N), dtype=torch.int64, device=self.device)
+            _check(lib().thfhe_kms_rotate_parties_dev(self.ck.h, op, ptr(x), ptr(y), self.rank * m, m, ptr(lev_mine), G))
+            if self.world == 1:
+                lev_all = lev_mine
+            elif self.host_staged:
+                parts = [torch.empty(lev_mine.shape, dtype=torch.int64) for _ in range(self.world)]
+                dist.all_gather(parts, lev_mine.cpu(), group=self.group)
+                lev_all = torch.cat(parts).to(self.device)
+            else:
+                lev_all = torch.empty((p.parties, G, p.l_lev, 2, p.N), dtype=torch.int64, device=self.device)
+                dist.all_gather_into_tensor(lev_all, lev_mine, group=self.group)
+            out = torch.empty((G, p.parties * p.n + 1), dtype=torch.int32, device=self.device)
+            _check(lib().thfhe_kms_finish_dev(self.ck.h, op, ptr(x), ptr(y), ptr(lev_all), ptr(out), G))
+        cur.wait_stream(self.stream)
+        return out
+
+
 def torch_all_gather(device=None):
     """all_gather over torch.distributed: every party's rotated accumulator travels once (sum of zero-initialised int64 tensors, an
     all-reduce: exact, and each party has exactly one owner).  device = a torch cuda device with backend "nccl" (RCCL), None with "gloo"."""
