@@ -780,7 +780,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     if (p->torus_bits != 64) return thfhe_fail(THFHE_E_UNSUPPORTED, "thfhe_mk_ctx_create is the Torus64 3-gen multi-key path");
     if ((p->N != 1024 && p->N != 2048) || p->k != 1) return thfhe_fail(THFHE_E_UNSUPPORTED, "only N = 1024 / 2048, k = 1 is implemented");
     if (p->N == 2048 && p->l > 3) return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 2048 needs decomposition length l <= 3");
-    if (p->parties < 1 || p->parties > 128) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= parties <= 128");
+    if (p->parties < 1 || p->parties > 512) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= parties <= 512");
     // digits beyond 10 bit are cut into balanced parts of <= 9 bit (N = 2048 only: the sets that use a wide base live on that ring,
     // J/mk_api.jl:214-298); |sum| <= 2 l parts N 2^(pw-1) 2^15 <= 2^36.6 stays inside the N = 2048 exactness bound
     const int parts = p->Bgbit > 10 ? (p->Bgbit + 8) / 9 : 1;
