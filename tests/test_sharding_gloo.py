@@ -104,3 +104,26 @@ def test_algorithmic_bytes_match_baseline_md():
     for name, (bk, ksk, total) in exp.items():
         ab = bench.algorithmic_bytes(thfhe.make_params(name))
         assert (ab["bk"], ab["ksk"], ab["total"]) == (bk, ksk, total), name
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,pset,batch", [("replicated", "SK-128", 256), ("party", "MK2", 128)])
+def test_bench_two_spawned_ranks_on_the_one_gpu(mode, pset, batch):
+    # The whole N > 1 path of bench.py on real hardware, as far as a one-GPU box allows: `python bench.py --gpus 2` spawns two ranks that SHARE the
+    # box's MI355X (device = LOCAL_RANK mod device count), rendezvous over gloo (RCCL refuses two ranks on one device), run their steps between
+    # barriers and print ONE line.  Replicated mode: each rank its own gate batch.  Party mode (BASELINE configs[4]'s shape on the 2-party set): one
+    # pipeline group of two ranks, one party each -- accumulator send/recv, broadcast of the extracted sample, all-gather of the key-switched parts,
+    # every output decrypted by bench.py itself (it raises on a wrong bit).
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--set", pset, "--batch", str(batch), "--mode", mode, "--steps", "2",
+                         "--warmup", "1", "--no-cpu-baseline"], env=_clean_env(THFHE_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["requested_gpus"] == 2 and res["config"]["mode"] == mode and res["bit_exact_decrypt_errors"] == 0
+    assert res["value"] > 0 and res["config"]["timing_backend"] == "gloo"
+    if mode == "party":
+        assert "1 group(s) x 2 rank(s), 1 parties per rank" in res["config"]["parallelism"]
