@@ -187,37 +187,6 @@ __device__ __forceinline__ void wave_fft_inv_q(int lane, cplx (&z)[8], cplx *xb,
     wave_transpose_hi3(z);
     invq_seg3(z, r);
 }
-// variant "qh": first transpose in registers, second through a 4.5 KiB buffer of doubles, real parts then imaginary parts (thfhe_lane.h)
-template <class Roots>
-__device__ __forceinline__ void wave_fft_fwd_qh(int lane, cplx (&z)[8], double *xr, const Roots &r, const W64 &w) {
-    fwdq_seg1(z, r);
-    wave_transpose_hi3(z);
-    fwdh_tw(z, w);
-    wave_sync();
-    xh_put_c<0>(lane, z, xr);
-    wave_sync();
-    xh_get_d<0>(lane, z, xr);
-    wave_sync();
-    xh_put_c<1>(lane, z, xr);
-    wave_sync();
-    xh_get_d<1>(lane, z, xr);
-    dft8<+1>(z);
-}
-template <class Roots>
-__device__ __forceinline__ void wave_fft_inv_qh(int lane, cplx (&z)[8], double *xr, const Roots &r, const W64 &w) {
-    invh_tw(z, w);
-    wave_sync();
-    xh_put_d<0>(lane, z, xr);
-    wave_sync();
-    xh_get_c<0>(lane, z, xr);
-    wave_sync();
-    xh_put_d<1>(lane, z, xr);
-    wave_sync();
-    xh_get_c<1>(lane, z, xr);
-    dft8<-1>(z);
-    wave_transpose_hi3(z);
-    invq_seg3(z, r);
-}
 // variant "qs" (multi-key kernels, whose LDS has no room for padded buffers): first transpose in registers, pass-1 twiddles from the
 // per-lane roots, second transpose through the XOR-swizzled 512-slot buffer -- one LDS crossing and no T1 table reads per transform
 template <class Roots>

@@ -373,48 +373,6 @@ THFHE_FN void invq_seg3(cplx (&z)[8], const LaneTw &t) {
     for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], cplx{THFHE_C_RE(m), THFHE_C_IM(m)});
 }
 
-// ---- variant "qh": as "q", but the LDS transpose (register index <-> lane bits 0..2) moves the real parts and then the imaginary
-// parts through ONE 4.5 KiB buffer of doubles instead of whole complex numbers through a 9 KiB buffer: the same padded slot maps on
-// 8-byte elements (conflict-free for ds_write_b64: 16 contiguous lanes cover the 32 banks once; for ds_read_b64: 32 lanes cover the 64
-// banks once -- xs_c / xs_d at stride 9 slots = 18 dwords), the same LDS-array cycles (16 B per lane and direction either way).  One
-// wavefront's DS instructions execute in issue order, so the imaginary parts may be written right behind the reads of the real parts
-// (no round trip in between).  The 36 KiB this frees let TWO independent 4-job workgroups share a CU (sk_blind_rotate_ring4_kernel).
-constexpr int kXhalfSlots = 8 * 72;  // doubles (4608 B)
-THFHE_FN void fwdh_tw(cplx (&z)[8], const W64 &w) {   // pass 2 + its twiddles, in registers
-    dft8<+1>(z);
-    cplx p[8];
-    w64_powers(w, p);
-#pragma unroll
-    for (int k1 = 1; k1 < 8; k1++) z[k1] = cmul(z[k1], p[k1]);
-}
-THFHE_FN void invh_tw(cplx (&z)[8], const W64 &w) {
-    dft8<-1>(z);
-    cplx p[8];
-    w64_powers(w, p);
-#pragma unroll
-    for (int j0 = 1; j0 < 8; j0++) z[j0] = cmul_conj(z[j0], p[j0]);
-}
-template <int PART>  // 0: real parts, 1: imaginary parts
-THFHE_FN void xh_put_c(int lane, const cplx (&z)[8], double *xr) {
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) xr[xs_c(k1, lane)] = PART ? z[k1].im : z[k1].re;
-}
-template <int PART>
-THFHE_FN void xh_get_d(int lane, cplx (&z)[8], const double *xr) {
-#pragma unroll
-    for (int j0 = 0; j0 < 8; j0++) (PART ? z[j0].im : z[j0].re) = xr[xs_d(j0, lane)];
-}
-template <int PART>
-THFHE_FN void xh_put_d(int lane, const cplx (&z)[8], double *xr) {
-#pragma unroll
-    for (int j0 = 0; j0 < 8; j0++) xr[xs_d(j0, lane)] = PART ? z[j0].im : z[j0].re;
-}
-template <int PART>
-THFHE_FN void xh_get_c(int lane, cplx (&z)[8], const double *xr) {
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) (PART ? z[k1].im : z[k1].re) = xr[xs_c(k1, lane)];
-}
-
 // ---- integer helpers ---------------------------------------------------------------------------------
 // coefficient q of X^a * p - p for p in LDS, a in [0, 2N)          (mul_by_monomial, J/rlwe.jl:130-131)
 THFHE_FN uint32_t rot_minus_self32(const int32_t *p, int q, int a2n, int N) {

@@ -272,124 +272,6 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// blind rotate + extract, throughput kernel with DECOUPLED wave pairs ("ring4"): the ring kernel's work per wave, but a workgroup is FOUR
-// waves = four jobs, one wave per SIMD, and TWO workgroups share a CU.  The two waves of a SIMD then belong to different workgroups with
-// their own key ring and their own barriers: when one of them waits at a hand-off or on the LDS, the other is somewhere else in its CMux
-// and fills the vector pipe -- in the eight-wave workgroup both waves of a SIMD reach every barrier together, the older one waits for
-// the younger one 22 k cycles per CMux and the pipe idles with them (profiles/r03_ring_variants.md).  Round 2 tried the split with
-// half-chunk ring pieces (twice the barriers); here the LDS transposes go through 4.5 KiB buffers of doubles (variant "qh"), which makes
-// room for a full three-slot ring per workgroup: 4 x (accumulator 8 KiB + buffer 4.5 KiB) + 3 x 8 KiB = 74 KiB, two workgroups per CU.
-// Every key chunk crosses the CU twice (once per workgroup): L2 traffic doubles, HBM traffic is still < 2 % of peak.
-// ------------------------------------------------------------------------------------------------------
-template <int L>
-__global__ __launch_bounds__(256, 2) void sk_blind_rotate_ring4_kernel(BRArgs a) {
-    __shared__ __attribute__((aligned(4096))) int32_t sAcc[4][2048];
-    __shared__ double sXh[4][kXhalfSlots];
-    __shared__ cplx sRing[3][512];
-    constexpr int ROWS = 2 * L;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
-    const LaneRoots roots{a.tw[576 + 2 * lane], a.tw[576 + 2 * lane + 1]};
-    const LaneTw tw = make_lane_tw(roots);
-    const long job = (long)blockIdx.x * 4 + wave;
-    const bool has_job = job < a.jobs;
-    int32_t *acc = sAcc[wave];
-    double *xr = sXh[wave];
-    const int32_t *bara = a.bara + (has_job ? job : 0) * a.n_pad;
-    const int Bgbit = a.Bgbit;
-    if (has_job) acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
-
-    const long total_chunks = (long)a.n * ROWS * 4;
-    const cplx *gsrc = a.bk + wave * 64 + lane;
-    long q_issue = 0;
-    int slot_issue = 0;
-    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sRing[0][0] + (uint32_t)wave * 1024u;
-    auto issue = [&]() {   // four waves: wave w brings slices w and w + 4 of the chunk
-        ring_dma(gsrc, ring_base + (uint32_t)slot_issue * 8192u);
-        ring_dma(gsrc + 4 * 64, ring_base + 4096u + (uint32_t)slot_issue * 8192u);
-        if (q_issue + 1 < total_chunks) {
-            gsrc += 512;
-            q_issue++;
-        }
-        slot_issue = slot_issue == 2 ? 0 : slot_issue + 1;
-    };
-    __syncthreads();
-    issue();
-    issue();
-    issue();
-    int slot_use = 0;
-    
-
-    for (int i = 0; i < a.n; i++) {
-        const int ai = bara[i];
-        const bool active = has_job && ai != 0;
-        const int a2n = ai & 2047;
-        cplx S[2][2][8];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int m = 0; m < 8; m++) S[c][h][m] = cplx{0.0, 0.0};
-        constexpr int NF = THFHE_RING_NF;   // rotated fields kept across the levels of a polynomial (register budget)
-        uint32_t fld[NF];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            cplx z[8];
-            if (active) {
-                // index / sign / subtraction once per accumulator polynomial, then one signed bit-field extract + one conversion per level
-                int a2n_r = a2n;
-                asm volatile("" : "+s"(a2n_r));  // opaque per row: the rotated LDS addresses are recomputed, not kept alive
-                if (r % L == 0) rotated_fields_keep<NF>(lane, acc + (r / L) * 1024, a2n_r, L, Bgbit, fld);
-                asm volatile("" : "+s"(a2n_r));
-                mixed_digits_z<NF>(lane, acc + (r / L) * 1024, a2n_r, (r % L) + 1, L, Bgbit, fld, z);
-                wave_fft_fwd_qh(lane, z, xr, tw, w64);
-            }
-            cplx bA[4], bB[4];
-#pragma unroll
-            for (int c4 = 0; c4 < 4; c4++) {
-                if (c4 == 0) ring_barrier<4>(); else ring_barrier<2>();
-                if (c4 > 0) issue();
-                const cplx *B = &sRing[slot_use][0];
-                if (active) {
-#pragma unroll
-                    for (int m = 0; m < 4; m++) bA[m] = B[m * 64 + lane];
-                    if (c4 > 0) {
-#pragma unroll
-                        for (int m = 0; m < 4; m++) cfma(S[(c4 - 1) >> 1][(c4 - 1) & 1][4 + m], z[4 + m], bB[m]);
-                    }
-#pragma unroll
-                    for (int m = 0; m < 4; m++) bB[m] = B[(4 + m) * 64 + lane];
-#pragma unroll
-                    for (int m = 0; m < 4; m++) cfma(S[c4 >> 1][c4 & 1][m], z[m], bA[m]);
-                }
-                slot_use = slot_use == 2 ? 0 : slot_use + 1;
-            }
-            ring_barrier<4>();  // the row's last chunk is read by all (its second half sits in bB): refill its slot before the next transform
-            issue();
-            if (active) {
-#pragma unroll
-                for (int m = 0; m < 4; m++) cfma(S[1][1][4 + m], z[4 + m], bB[m]);
-            }
-        }
-        if (active) {
-            wave_sync();
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                wave_fft_inv_qh(lane, S[c][0], xr, tw, w64);
-                wave_fft_inv_qh(lane, S[c][1], xr, tw, w64);
-                acc_update16(lane, acc + c * 1024, S[c][0], S[c][1]);
-            }
-            wave_sync();
-        }
-    }
-    
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (has_job) extract16(lane, acc, acc + 1024, a.out + job * 1025);
-}
-
-// ------------------------------------------------------------------------------------------------------
 // blind rotate + extract, latency kernel ("cooperative", second generation): one 512-thread workgroup = ONE job.  For the small
 // batches the reference's gate-at-a-time callers produce (boots* shims, ripple-carry circuits: 855 of the 1 033 levels of the KNN
 // decision hold 1-3 gates) the ring kernel leaves 7/8 of a CU idle; here the work of one CMux is spread over the eight waves and
@@ -814,8 +696,6 @@ void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
     if (variant == 8) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 0>), grid, block, 0, s, a); return; }
     if (variant == 3) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 3>), grid, block, 0, s, a); return; }   // forward in registers, inverse through the LDS
 #endif
-    static const int gen = std::getenv("THFHE_RING_GEN") ? std::atoi(std::getenv("THFHE_RING_GEN")) : 0;   // developer A/B
-    if (gen == 4) { hipLaunchKernelGGL((sk_blind_rotate_ring4_kernel<L>), dim3((unsigned)((a.jobs + 3) / 4)), dim3(256), 0, s, a); return; }
     hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 1>), grid, block, 0, s, a);
 }
 
