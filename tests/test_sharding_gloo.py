@@ -127,3 +127,15 @@ def test_bench_two_spawned_ranks_on_the_one_gpu(mode, pset, batch):
     assert res["value"] > 0 and res["config"]["timing_backend"] == "gloo"
     if mode == "party":
         assert "1 group(s) x 2 rank(s), 1 parties per rank" in res["config"]["parallelism"]
+
+
+def test_bench_eight_spawned_ranks_party_topology_of_configs4():
+    # BASELINE.json configs[4] as the driver would ask for it on an 8-GPU node: `python bench.py --gpus 8 --mode party --set MK4-N2048` -- eight
+    # ranks spawned by bench.py itself, two pipeline groups of four ranks, one party per rank (dry run: rendezvous + barriers, no GPU)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-topology", "--mode", "party", "--set", "MK4-N2048"],
+                        env=_clean_env(THFHE_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    res = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 8 and res["slowest_rank_time"] == 8.0
+    topo = res["party_topology"]
+    assert [t["group"] for t in topo] == [0, 0, 0, 0, 1, 1, 1, 1] and [t["parties"] for t in topo] == [[0, 1], [1, 2], [2, 3], [3, 4]] * 2
