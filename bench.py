@@ -150,10 +150,13 @@ def dist_setup(n_gpus):
 
 
 def cpu_baseline(K, p_name, mk, xa, xb, gpu_out, per_thread):
-    """Time the CPU oracle (exact-integer restatement of the reference path, OpenMP over gates = the reference's only parallel
-    pattern, src/KNN_medical_data.cpp:681) on the first gates of the same workload, on the CPUs this process may really use
-    (affinity mask capped by the cgroup quota); median of 3 runs; also cross-check the GPU output on the sample.
-    Single-key: J/bootstrap.jl + J/keyswitch.jl restated; 3-gen multi-key: J/3gen_mk_internals.jl:59-116 + J/mk_internals.jl:730-744."""
+    """Time the CPU oracle on the first gates of the same workload, OpenMP over gates (the reference's only parallel pattern,
+    src/KNN_medical_data.cpp:681) on the CPUs this process may really use (affinity mask capped by the cgroup quota); median of 3 runs.
+    Single-key: the timed engine is the oracle's restatement of what the reference's CPU path computes -- tgsw_extern_mul on the folded
+    Complex{Float64} transform (J/tgsw.jl:146-150, J/polynomials.jl:208-247; same algorithm class as libtfhe's FFT) -- and the exact-integer
+    engine (64-bit NTT) is timed next to it on a smaller sample and is the one the GPU output is compared with bit for bit.
+    3-gen multi-key (J/3gen_mk_internals.jl:59-116 + J/mk_internals.jl:730-744): the exact engine only (the reference's Float64 transform of
+    Torus64 words is lossy by construction)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     threads = O.usable_cpus()
@@ -161,32 +164,56 @@ def cpu_baseline(K, p_name, mk, xa, xb, gpu_out, per_thread):
     orc = (O.MKOracle if mk else O.Oracle)(p, K.bk, K.ksk)
     L = O.lib()
     L.oracle_set_threads(threads)
-    sample = min(per_thread * threads, xa.shape[0])
+
+    def timed(n_gates, engine, reps):
+        runs, ref = [], None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ref = orc.gates(O.NAND, xa[:n_gates], xb[:n_gates], schoolbook=engine)
+            runs.append(time.perf_counter() - t0)
+        return ref, sorted(runs)[len(runs) // 2], runs
+
+    exact_n = min((1 if mk else 8) * threads if per_thread is None else per_thread * threads, xa.shape[0])
     orc.gates(O.NAND, xa[:threads], xb[:threads])   # warm the NTT tables and every thread's scratch arena
-    runs = []
+    ref, dt_exact, runs_exact = timed(exact_n, 0, 3)
+    exact = bool(np.array_equal(ref, gpu_out[:exact_n]))
+    exact_obj = dict(value=exact_n / dt_exact, sample_gates=exact_n, runs_s=[round(r, 3) for r in runs_exact], gpu_bit_exact_on_sample=exact,
+                     engine="exact-integer oracle (64-bit NTT mod 2^64 - 2^32 + 1, centred lifting): the checker of every parity test")
+    aff = len(os.sched_getaffinity(0))
+    if mk:
+        L.oracle_set_threads(1)
+        t0 = time.perf_counter()
+        orc.gates(O.NAND, xa[:1], xb[:1])
+        single = 1.0 / (time.perf_counter() - t0)
+        L.oracle_set_threads(threads)
+        value = exact_obj["value"]
+        return dict(value=value, unit="gates/s", cores=threads, threads=threads, kind="port", per_thread_gates_per_s=value / threads,
+                    single_thread_value=single, scaling_efficiency=value / (threads * single), affinity_cpus=aff, runs_s=exact_obj["runs_s"],
+                    sample=f"first {exact_n} NAND gates of the same batch, exact-integer MK oracle (64-bit NTT), OpenMP schedule(dynamic) over gates on "
+                           f"{threads} threads (cgroup CPU quota; the affinity mask shows {aff}), median of 3 runs = {dt_exact:.2f} s",
+                    gpu_bit_exact_on_sample=exact)
+    fft_n = min((64 if per_thread is None else 8 * per_thread) * threads, xa.shape[0])
+    orc.gates(O.NAND, xa[:threads], xb[:threads], schoolbook=2)   # builds the transformed key (J/bootstrap.jl:11-12) once
+    ref_fft, dt, runs = timed(fft_n, 2, 3)
+    same_bits = bool(np.array_equal(K.decrypt(ref_fft), K.decrypt(gpu_out[:fft_n])))
+    L.oracle_set_threads(1)
+    n1 = min(4, fft_n)
+    one = []
     for _ in range(3):
         t0 = time.perf_counter()
-        ref = orc.gates(O.NAND, xa[:sample], xb[:sample])
-        runs.append(time.perf_counter() - t0)
-    dt = sorted(runs)[1]
-    exact = bool(np.array_equal(ref, gpu_out[:sample]))
-    L.oracle_set_threads(1)
-    n1 = min(4 if not mk else 1, sample)
-    one = []
-    for _ in range(3 if not mk else 1):
-        t0 = time.perf_counter()
-        orc.gates(O.NAND, xa[:n1], xb[:n1])
+        orc.gates(O.NAND, xa[:n1], xb[:n1], schoolbook=2)
         one.append((time.perf_counter() - t0) / n1)
     L.oracle_set_threads(threads)
-    single = 1.0 / sorted(one)[len(one) // 2]
-    value = sample / dt
+    single = 1.0 / sorted(one)[1]
+    value = fft_n / dt
     return dict(value=value, unit="gates/s", cores=threads, threads=threads, kind="port",
                 per_thread_gates_per_s=value / threads, single_thread_value=single, scaling_efficiency=value / (threads * single),
-                affinity_cpus=len(os.sched_getaffinity(0)), runs_s=[round(r, 3) for r in runs],
-                sample=f"first {sample} NAND gates of the same batch ({per_thread} per thread), exact-integer oracle (64-bit NTT engine, per-thread "
-                       f"scratch, no allocation in the CMux loop; NOT libtfhe's AVX FFT / Julia's FFT), OpenMP schedule(dynamic) over gates on {threads} threads "
-                       f"(cgroup CPU quota; the affinity mask shows {len(os.sched_getaffinity(0))}), median of 3 runs = {dt:.2f} s",
-                gpu_bit_exact_on_sample=exact)
+                affinity_cpus=aff, runs_s=[round(r, 3) for r in runs],
+                sample=f"first {fft_n} NAND gates of the same batch with the reference's own arithmetic restated in C: tgsw_extern_mul on the folded "
+                       f"Complex{{Float64}} transform (J/tgsw.jl:146-150, J/polynomials.jl:208-247; plain radix-2 FFT, no AVX assembly as libtfhe's spqlios), "
+                       f"OpenMP schedule(dynamic) over gates on {threads} threads (cgroup CPU quota; the affinity mask shows {aff}), median of 3 runs = {dt:.2f} s",
+                decrypts_like_gpu_on_sample=same_bits, words_equal_to_gpu_frac=float((ref_fft == gpu_out[:fft_n]).mean()),
+                gpu_bit_exact_on_sample=exact, exact_oracle=exact_obj)
 
 
 def load_counters(param_set, batch, kernel):
@@ -335,7 +362,7 @@ def main():
     ap.add_argument("--pipeline-chunks", type=int, default=0,
                     help="--mode party: slices of a group's batch in flight along the party pipeline (0 = auto: one per 256 gates, 1 when a group is one rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-per-thread", type=int, default=None, help="gates per host thread in the CPU baseline sample (default 8; 1 for multi-key sets)")
+    ap.add_argument("--cpu-per-thread", type=int, default=None, help="gates per host thread in the exact-oracle sample of the CPU baseline (default 8; 1 for multi-key sets; the FFT-engine sample is 8x that)")
     ap.add_argument("--dry-topology", action="store_true", help="rank start-up + rendezvous + barrier only (no GPU): rehearsal of --gpus N")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -359,7 +386,7 @@ def main():
 
     p = thfhe.make_params(args.set)
     mk = p.torus_bits == 64
-    per_thread = args.cpu_per_thread if args.cpu_per_thread is not None else (1 if mk else 8)
+    per_thread = args.cpu_per_thread
     cpu_ok = world == 1 and not args.no_cpu_baseline and p.parties * p.n * (p.N // 1024) <= 4500   # bounded sample: <= ~30 s of host work
 
     if args.mode == "party":

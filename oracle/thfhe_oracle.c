@@ -9,6 +9,13 @@
  *     the cpu_baseline timing).  tests/test_oracle_units.py checks NTT == schoolbook.
  * The GPU product uses a third, independent method (split-limb FP64 FFT), so GPU == oracle is a
  * genuine cross-check.
+ *
+ * Engine 2 (single-key path only) is NOT exact: it restates the arithmetic the reference really runs -- the folded N/2-point
+ * Complex{Float64} transform of J/polynomials.jl:81-247 under tgsw_extern_mul (J/tgsw.jl:146-150), products of full 32-bit torus
+ * words, rounded back with to_int32 -- so its low bits carry FFT rounding noise (far below the ciphertext noise), as the
+ * reference's own outputs do.  It exists (a) to show that the exact engines and the reference's approximate path decrypt alike and
+ * differ by that noise only (tests/test_oracle_units.py), (b) as the cpu_baseline of bench.py: the same algorithm class and cost as
+ * the reference's CPU path, not the ~3x more expensive exact NTT.
  */
 #include "thfhe_oracle.h"
 
@@ -25,7 +32,7 @@ typedef unsigned __int128 u128;
  * thread, kept for the life of the thread (OpenMP workers persist), so `oracle_gates` scales with the host's cores
  * instead of serialising on the allocator */
 enum { SCR_MUX = 0, SCR_EXT_DIG, SCR_EXT_NTT, SCR_EXT_PROD, SCR_BOOT, SCR_KS, SCR_GATE, SCR_MKMUX, SCR_MKEXT_DIG, SCR_MKEXT_NTT,
-       SCR_MKEXT_PROD, SCR_MKBOOT, SCR_MKKS, SCR_MKGATE, SCR_SLOTS };
+       SCR_MKEXT_PROD, SCR_MKBOOT, SCR_MKKS, SCR_MKGATE, SCR_EXT_FFT, SCR_SLOTS };
 static __thread void *scr_ptr[SCR_SLOTS];
 static __thread size_t scr_cap[SCR_SLOTS];
 static void *scr(int slot, size_t bytes) {
@@ -314,6 +321,108 @@ void oracle_set_threads(int n) {
 }
 
 /* ============================================================================================
+ * Engine 2: the reference's double-precision transform            J/polynomials.jl:81-247
+ *   ForwardTransformPlan (:81-95): coeffs[k] = exp(-2 pi i k / (2N)), plan_fft of length N/2
+ *   forward_transform (:208-214): buffer = (c[1:N/2] - i c[N/2+1:N]) .* coeffs ; fft(buffer)
+ *   inverse_transform (:224-242): buffer = ifft(x) ; buffer = conj(buffer) .* coeffs ; to_int32 of real / imaginary parts
+ *   to_int32(Float64) (:217-218): round(Int64, x) (ties to even), low 32 bits
+ * fft = sum_j x_j exp(-2 pi i j k / M) (Julia / FFTW sign convention), ifft its inverse with 1/M.
+ * ========================================================================================== */
+typedef struct {
+    double re, im;
+} cd;
+typedef struct {
+    int M;      /* N / 2 */
+    cd *w;      /* exp(-2 pi i t / M), t < M/2 */
+    cd *twist;  /* exp(-2 pi i k / (2N)), k < M */
+    int *rev;
+} fft_plan;
+static fft_plan g_fft[2];
+static const fft_plan *fft_get_plan(int N) {
+    fft_plan *P = &g_fft[N == 1024 ? 0 : 1];
+    if (P->M) return P;
+#pragma omp critical(fft_plan_init)
+    if (!P->M) {
+        const int M = N / 2;
+        int lg = 0;
+        while ((1 << lg) < M) lg++;
+        cd *w = (cd *)malloc(sizeof(cd) * (size_t)(M / 2)), *tw = (cd *)malloc(sizeof(cd) * (size_t)M);
+        int *rev = (int *)malloc(sizeof(int) * (size_t)M);
+        const long double PI = 3.14159265358979323846264338327950288L;
+        for (int t = 0; t < M / 2; t++) w[t] = (cd){(double)cosl(-2.0L * PI * t / M), (double)sinl(-2.0L * PI * t / M)};
+        for (int k = 0; k < M; k++) tw[k] = (cd){(double)cosl(-PI * k / N), (double)sinl(-PI * k / N)};
+        for (int k = 0; k < M; k++) {
+            int r = 0;
+            for (int b = 0; b < lg; b++) r |= ((k >> b) & 1) << (lg - 1 - b);
+            rev[k] = r;
+        }
+        P->w = w, P->twist = tw, P->rev = rev;
+#pragma omp flush
+        P->M = M;
+    }
+    return P;
+}
+/* in-place radix-2 decimation in time; sign = -1: fft, +1: unnormalised ifft */
+static void fft_run(cd *a, const fft_plan *P, int sign) {
+    const int M = P->M;
+    for (int k = 0; k < M; k++) {
+        const int r = P->rev[k];
+        if (r > k) {
+            cd t = a[k];
+            a[k] = a[r];
+            a[r] = t;
+        }
+    }
+    for (int half = 1; half < M; half <<= 1) {
+        const int step = M / (2 * half);
+        for (int base = 0; base < M; base += 2 * half)
+            for (int j = 0; j < half; j++) {
+                const cd w = P->w[j * step];
+                const double wi = sign < 0 ? w.im : -w.im;
+                cd *x = a + base + j, *y = x + half;
+                const double tr = y->re * w.re - y->im * wi, ti = y->re * wi + y->im * w.re;
+                y->re = x->re - tr, y->im = x->im - ti;
+                x->re += tr, x->im += ti;
+            }
+    }
+}
+static void fft_forward_transform(const int32_t *c, int N, cd *out) { /* J/polynomials.jl:208-214 */
+    const fft_plan *P = fft_get_plan(N);
+    const int M = N / 2;
+    for (int k = 0; k < M; k++) {
+        const double re = (double)c[k], im = -(double)c[k + M];
+        out[k] = (cd){re * P->twist[k].re - im * P->twist[k].im, re * P->twist[k].im + im * P->twist[k].re};
+    }
+    fft_run(out, P, -1);
+}
+static int32_t fft_to_int32(double x) { /* :217-218 */
+    return (int32_t)(uint32_t)(uint64_t)(int64_t)nearbyint(x);
+}
+static void fft_inverse_transform(cd *x, int N, int32_t *out) { /* J/polynomials.jl:224-242; x is consumed */
+    const fft_plan *P = fft_get_plan(N);
+    const int M = N / 2;
+    fft_run(x, P, +1);
+    const double inv = 1.0 / M;
+    for (int k = 0; k < M; k++) {
+        const double re = x[k].re * inv, im = -x[k].im * inv; /* conj(buffer) */
+        out[k] = fft_to_int32(re * P->twist[k].re - im * P->twist[k].im);
+        out[k + M] = fft_to_int32(re * P->twist[k].im + im * P->twist[k].re);
+    }
+}
+
+/* transformed_mul(x::IntPolynomial, y::TorusPolynomial): inverse_transform(forward_transform(x) * forward_transform(y))     J/polynomials.jl:245-247
+ * (the product src/ntt-test.cpp:57-93 compares with the schoolbook one on its low 31 bits) */
+void oracle_fft_polymul32(const int32_t *x, const int32_t *y, int32_t N, int32_t *out) {
+    const int M = N / 2;
+    cd *a = (cd *)malloc(sizeof(cd) * 2 * (size_t)M), *b = a + M;
+    fft_forward_transform(x, N, a);
+    fft_forward_transform(y, N, b);
+    for (int j = 0; j < M; j++) a[j] = (cd){a[j].re * b[j].re - a[j].im * b[j].im, a[j].re * b[j].im + a[j].im * b[j].re};
+    fft_inverse_transform(a, N, out);
+    free(a);
+}
+
+/* ============================================================================================
  * single-key context
  * ========================================================================================== */
 struct oracle_ctx {
@@ -321,6 +430,7 @@ struct oracle_ctx {
     const int32_t *bk;  /* borrowed */
     const int32_t *ksk; /* borrowed */
     uint64_t *bk_ntt;   /* [n][(k+1)l][k+1][N] NTT domain */
+    void *bk_fft;       /* engine 2: [n][(k+1)l][k+1][N/2] Complex{Float64} = BootstrapKey's TransformedTGswSample (J/bootstrap.jl:11-12), built on first use */
 };
 
 oracle_ctx *oracle_ctx_create(const oracle_params *p, const int32_t *bk, const int32_t *ksk) {
@@ -345,7 +455,22 @@ oracle_ctx *oracle_ctx_create(const oracle_params *p, const int32_t *bk, const i
 void oracle_ctx_destroy(oracle_ctx *c) {
     if (!c) return;
     free(c->bk_ntt);
+    free(c->bk_fft);
     free(c);
+}
+static const cd *ctx_bk_fft(const oracle_ctx *cc) {
+    oracle_ctx *c = (oracle_ctx *)cc;
+    if (c->bk_fft) return (const cd *)c->bk_fft;
+#pragma omp critical(bk_fft_init)
+    if (!c->bk_fft) {
+        const int N = c->p.N;
+        const size_t polys = (size_t)c->p.n * (c->p.k + 1) * c->p.l * (c->p.k + 1);
+        cd *t = (cd *)malloc(polys * (size_t)(N / 2) * sizeof(cd));
+        for (size_t q = 0; q < polys; q++) fft_forward_transform(c->bk + q * N, N, t + q * (size_t)(N / 2));
+#pragma omp flush
+        c->bk_fft = t;
+    }
+    return (const cd *)c->bk_fft;
 }
 
 /* tgsw_extern_mul: out[c] = sum_{j,p} digit_p(tmp[j]) (*) BK_i[j*l+p][c]     J/tgsw.jl:146-156 */
@@ -353,6 +478,25 @@ static void extern_mul32(const oracle_ctx *c, int32_t i, const int32_t *tmp, int
     const int N = c->p.N, k = c->p.k, l = c->p.l, rows = (k + 1) * l;
     int32_t *dig = (int32_t *)scr(SCR_EXT_DIG, sizeof(int32_t) * (size_t)rows * N);
     for (int j = 0; j <= k; j++) oracle_decompose32(tmp + (size_t)j * N, N, l, c->p.Bgbit, dig + (size_t)j * l * N);
+    if (use_schoolbook == 2) { /* tgsw_extern_mul as the reference runs it: J/tgsw.jl:146-150 on J/polynomials.jl:208-247 */
+        const int M = N / 2;
+        const cd *bk = ctx_bk_fft(c) + (size_t)i * rows * (k + 1) * M;
+        cd *d = (cd *)scr(SCR_EXT_FFT, sizeof(cd) * (size_t)(rows + 1) * M), *acc = d + (size_t)rows * M;
+        for (int r = 0; r < rows; r++) fft_forward_transform(dig + (size_t)r * N, N, d + (size_t)r * M);
+        for (int cc = 0; cc <= k; cc++) {
+            for (int j = 0; j < M; j++) {
+                double sr = 0.0, si = 0.0;
+                for (int r = 0; r < rows; r++) {
+                    const cd x = d[(size_t)r * M + j], y = bk[((size_t)r * (k + 1) + cc) * M + j];
+                    sr += x.re * y.re - x.im * y.im;
+                    si += x.re * y.im + x.im * y.re;
+                }
+                acc[j] = (cd){sr, si};
+            }
+            fft_inverse_transform(acc, N, out + (size_t)cc * N);
+        }
+        return;
+    }
     if (use_schoolbook) {
         int32_t *prod = (int32_t *)scr(SCR_EXT_PROD, sizeof(int32_t) * N);
         memset(out, 0, sizeof(int32_t) * (size_t)(k + 1) * N);

@@ -73,7 +73,9 @@ oracle_ctx *oracle_ctx_create(const oracle_params *p, const int32_t *bk, const i
 void oracle_ctx_destroy(oracle_ctx *c);
 
 /* acc (k+1 polys of N) += BK_i (.) (X^barai * acc - acc)           J/bootstrap.jl:19-23
- * use_schoolbook != 0 -> O(N^2) reference multiply, else NTT multiply (bit-identical). */
+ * use_schoolbook = 1 -> O(N^2) reference multiply, 0 -> NTT multiply (bit-identical); single-key functions also take 2 -> the reference's
+ * own APPROXIMATE Complex{Float64} transform (J/polynomials.jl:208-247): same decryptions, low bits differ by FFT rounding noise. */
+void oracle_fft_polymul32(const int32_t *x, const int32_t *y, int32_t N, int32_t *out); /* transformed_mul, J/polynomials.jl:245-247: the reference's approximate Complex{Float64} product */
 void oracle_mux_rotate(const oracle_ctx *c, int32_t i, int32_t barai, int32_t *acc, int use_schoolbook);
 /* x: LWE(n) record -> out: LWE(kN) record, mu = output message     J/bootstrap.jl:75-88 */
 void oracle_bootstrap_wo_keyswitch(const oracle_ctx *c, int32_t mu, const int32_t *x, int32_t *out, int use_schoolbook);

@@ -111,6 +111,7 @@ def lib():
         "oracle_decompose32": (None, [i32p, C.c_int32, C.c_int32, C.c_int32, i32p]),
         "oracle_decompose64": (None, [i64p, C.c_int32, C.c_int32, C.c_int32, i64p]),
         "oracle_polymul_schoolbook32": (None, [i32p, i32p, C.c_int32, i32p]),
+        "oracle_fft_polymul32": (None, [i32p, i32p, C.c_int32, i32p]),
         "oracle_polymul_schoolbook64": (None, [i64p, i64p, C.c_int32, i64p]),
         "oracle_polymul_ntt32": (None, [i32p, i32p, C.c_int32, i32p]),
         "oracle_polymul_ntt64": (None, [i64p, i64p, C.c_int32, i64p]),

@@ -225,3 +225,42 @@ def test_blind_rotate_skips_zero_bara(O, sk_small):
     tv = np.full(p.N, 1 << 29, np.int32); rot = np.zeros(p.N, np.int32)
     O.lib().oracle_mul_by_monomial32(O.p32(tv), -barb, p.N, O.p32(rot))
     assert np.all(u[:p.N] == 0) and u[p.N] == rot[0]
+
+
+def test_reference_fft_path_equals_the_exact_product_on_its_low_bits(O):
+    # src/ntt-test.cpp:57-93 in the reference: the FFT product (torusPolynomialAddMulRFFT) must equal the schoolbook negacyclic product on the low
+    # 31 bits.  Here: engine 2 of the oracle = the reference's Complex{Float64} transform restated (J/polynomials.jl:208-247, transformed_mul :245-247)
+    # against the exact schoolbook product.  With gadget-sized small operands (|d| <= 64) and random Torus32 words the sums stay near 2^43 and the
+    # double transform is exact; with every word at +-2^31 and |d| = 512 (2^50) its low bits are rounding noise, the top 22 bits still agree.
+    L = O.lib()
+    rng = np.random.default_rng(44)
+    for dmax, exact in ((64, True), (512, False)):
+        a = rng.integers(-dmax, dmax, 1024).astype(np.int32)
+        b = (rng.integers(-2**31, 2**31, 1024) if exact else np.where(rng.integers(0, 2, 1024) == 1, 2**31 - 1, -2**31)).astype(np.int32)
+        if not exact:
+            a = (rng.integers(0, 2, 1024) * (2 * dmax - 1) - dmax).astype(np.int32)
+        ref, got = np.zeros(1024, np.int32), np.zeros(1024, np.int32)
+        L.oracle_polymul_schoolbook32(O.p32(a), O.p32(b), 1024, O.p32(ref))
+        L.oracle_fft_polymul32(O.p32(a), O.p32(b), 1024, O.p32(got))
+        diff = (got.astype(np.int64) - ref.astype(np.int64) + 2**31) % 2**32 - 2**31
+        if exact:
+            assert np.array_equal(got, ref)
+        else:
+            assert np.abs(diff).max() < 2**10, np.abs(diff).max()
+
+
+def test_reference_fft_engine_gate_decrypts_like_the_exact_engines(O, sk_small):
+    # gate level: bootstrap with tgsw_extern_mul as the reference runs it (engine 2) against the exact engine -- same decryptions, phases equal up to
+    # FFT rounding noise far below the ciphertext noise (observed: word for word equal at these magnitudes)
+    p, K, orc = sk_small
+    rng = np.random.default_rng(45)
+    a, b = rng.integers(0, 2, 6), rng.integers(0, 2, 6)
+    ca, cb = K.encrypt_bits(a, 2.0**-15, 71), K.encrypt_bits(b, 2.0**-15, 72)
+    for op in (O.NAND, O.XOR):
+        ex = orc.gates(op, ca, cb)
+        ff = orc.gates(op, ca, cb, schoolbook=2)
+        assert np.array_equal(K.decrypt_bits(ff), K.decrypt_bits(ex))
+        d = (K.phases(ff).astype(np.int64) - K.phases(ex).astype(np.int64) + 2**31) % 2**32 - 2**31
+        assert np.abs(d).max() < 2**12      # 2^-20 of the torus; the ciphertext noise is ~2^-7.6 after bootstrapping
+    ff = orc.gates(O.MUX, ca, cb, cb[::-1].copy(), schoolbook=2)
+    assert np.array_equal(K.decrypt_bits(ff), K.decrypt_bits(orc.gates(O.MUX, ca, cb, cb[::-1].copy())))
