@@ -237,6 +237,36 @@ def test_mk4_n2048_full_size(O):
     ck.close()
 
 
+def test_mk_n2048_pair_kernel_bit_exact(O):
+    # two gates per workgroup on the ring of degree 2048 (mk_blind_rotate_pair2k_kernel: two half passes per step, digits extracted twice):
+    # forced for small odd batches, zero mask words in one gate of a pair, a lone last gate; l = 3 and l = 2 shapes; the wide-base shape
+    # (MK16 gadget: one level, three digit parts) as well.  Against the oracle AND against the one-gate kernel.
+    import thfhe
+    for name, over in (("MK4-N2048", dict(n=40, parties=2)), ("MK2", dict(n=33, N=2048)), ("MK16", dict(n=12, parties=3))):
+        p = O.make_params(name, **over)
+        s = O.SIGMAS[name]
+        K = O.MKKeys(p, 21, s["bk"], s["ks"])
+        orc = O.MKOracle(p, K.bk, K.ksk)
+        ck = thfhe.MKCloudKey(thfhe.make_params(**p.as_dict()), K.bk, K.ksk, device=0)
+        rng = np.random.default_rng(5)
+        a, b, c = (rng.integers(0, 2, 7) for _ in range(3))
+        ca, cb, cc = (K.encrypt_bits(v, s["lwe"], 300 + q) for q, v in enumerate((a, b, c)))
+        ca[0, 3] = cb[0, 3] = 0               # bara = 0 for gate 0 at i = 3, not for gate 1
+        ca[3, p.n + 2] = cb[3, p.n + 2] = 0   # second party's range, odd gate of a pair
+        ca[6, 0] = cb[6, 0] = 0               # the lone gate of the last workgroup
+        single = {op: ck.gates(op, *args) for op, args in ((O.NAND, (ca, cb)), (O.AND3, (ca, cb, cc)))}
+        ck.set_pair_threshold(0)
+        assert "pair2k" in ck.rotation_kernel_name(7)
+        for op, args in ((O.NAND, (ca, cb)), (O.XOR, (ca, cb)), (O.AND3, (ca, cb, cc)), (O.MUX, (ca, cb, cc))):
+            got = ck.gates(op, *args)
+            assert np.array_equal(got, orc.gates(op, *args)), (name, op)
+            if op in single:
+                assert np.array_equal(got, single[op]), (name, op)
+        fa, fb = K.encrypt_bits(a, s["lwe"], 310), K.encrypt_bits(b, s["lwe"], 311)   # untouched ciphertexts for the truth table
+        assert np.array_equal(K.decrypt_bits(ck.gates(thfhe.NAND, fa, fb)), ~(a.astype(bool) & b.astype(bool)))
+        ck.close()
+
+
 def test_mk_pair_kernel_bit_exact(O, mk2gpu):
     # throughput kernel (two gates per workgroup share every key chunk): forced for small odd batches, incl. a zero mod-switched
     # mask word in one gate of a pair (that gate skips the CMux, its partner does not) and a lone last gate

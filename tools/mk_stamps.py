@@ -13,6 +13,9 @@ ck = thfhe.MKCloudKey(p, K.bk, K.ksk)
 rng = np.random.default_rng(0)
 xa, xb = K.encrypt(rng.integers(0, 2, B), 1), K.encrypt(rng.integers(0, 2, B), 2)
 ck.set_profiling(True)
+PAIR = len(sys.argv) > 3 and sys.argv[3] == "pair"   # two gates per workgroup (mk_blind_rotate_pair2k_kernel)
+if PAIR:
+    ck.set_pair_threshold(0)
 for _ in range(2):
     out = ck.gates(thfhe.NAND, xa, xb)
 t = ck.last_timings()
@@ -21,8 +24,10 @@ buf = np.zeros(B * 64, np.uint64)
 L.thfhe_debug_read_stamps_mk.argtypes = [C.c_void_p, C.c_size_t]
 assert L.thfhe_debug_read_stamps_mk(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
 steps = p.parties * p.n
-st = buf.reshape(B, 8, 8)[:, :, :6].astype(np.float64) / steps
+st = buf.reshape(B, 8, 8)[:B // 2 if PAIR else B, :, :6].astype(np.float64) / steps
 names = ["F: digits + 2 half transforms + publish", "wait barrier 1", "M: 4l chunk multiplies (+ key requests)", "I: 2 half inverses + atomics", "wait barrier 2", "wait barrier 3"]
+if PAIR:
+    names = ["F: digits + half transform, both half passes", "wait barriers after F", "M: 2 x 2l chunk multiplies into two gates", "I: 4 half inverses + atomics", "wait barriers after M", "wait barrier after I"]
 print(f"{name} batch {B}: blind rotate {t['blind_rotate_ms']:.3f} ms; cycles per CMux step and wave")
 for q, nm in enumerate(names):
     print(f"  {nm:42s} mean {st[:, :, q].mean():9.1f}  " + " ".join(f"{st[:, w, q].mean():8.0f}" for w in range(8)))

@@ -720,6 +720,43 @@ THFHE_FN void invt_seg3(int lane, cplx (&z)[8], const cplx *xbuf, const cplx *T1
 #pragma unroll
     for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], e32(T * m));
 }
+// "qs" form of the twisted halves (the two-gate N = 2048 kernel, whose LDS has no room for the two T1 tables): the pass-1 twiddles are
+// rebuilt from per-lane roots, T1_T[k0][lane] = b_T s^k0 with b_T = zeta^(T lane), s = zeta^(8 lane), and the first transpose happens in
+// registers (wave_transpose_hi3) -- same spectra order, so key spectra made by the table variant multiply with these.
+template <int T>
+THFHE_FN void fwdtq_seg1(cplx (&z)[8], const LaneRoots &r) {
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], e32(T * m));
+    dft8<+1>(z);
+    const cplx s2 = cmul(r.s, r.s);
+    cplx e = r.b, o = cmul(r.b, r.s);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += 2) {
+        z[k0] = cmul(z[k0], e);
+        z[k0 + 1] = cmul(z[k0 + 1], o);
+        if (k0 < 6) {
+            e = cmul(e, s2);
+            o = cmul(o, s2);
+        }
+    }
+}
+template <int T>
+THFHE_FN void invtq_seg3(cplx (&z)[8], const LaneRoots &r) {
+    const cplx s2 = cmul(r.s, r.s);
+    cplx e = r.b, o = cmul(r.b, r.s);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += 2) {
+        z[k0] = cmul_conj(z[k0], e);
+        z[k0 + 1] = cmul_conj(z[k0 + 1], o);
+        if (k0 < 6) {
+            e = cmul(e, s2);
+            o = cmul(o, s2);
+        }
+    }
+    dft8<-1>(z);
+#pragma unroll
+    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], e32(T * m));
+}
 // radix-2 split of the 16 folded points a lane holds (z[m] <-> j = lane + 64 m) and its inverse (unnormalised: x2)
 THFHE_FN void split2048(const cplx (&z)[16], cplx (&y0)[8], cplx (&y1)[8]) {
     constexpr double R = 0.70710678118654752440;
@@ -816,6 +853,14 @@ inline void make_lane_roots_1024(cplx *roots /*128*/) {
         long double a = PI * (long double)lane / 1024.0L, b = PI * (long double)(4 * lane) / 1024.0L;
         roots[2 * lane] = cplx{(double)cosl(a), (double)sinl(a)};
         roots[2 * lane + 1] = cplx{(double)cosl(b), (double)sinl(b)};
+    }
+}
+// N = 2048, "qs" form: the common ratio s[lane] = exp(i pi 8 lane / 2048) of the pass-1 twiddles (b_T = T1_T[0][lane] comes from the tables)
+inline void make_lane_ratio_2048(cplx *s /*64*/) {
+    const long double PI = 3.14159265358979323846264338327950288L;
+    for (int lane = 0; lane < 64; lane++) {
+        long double a = PI * (long double)(8 * lane) / 2048.0L;
+        s[lane] = cplx{(double)cosl(a), (double)sinl(a)};
     }
 }
 // N = 2048: T1_T[k0*64 + lane] = exp(i pi lane (8 k0 + T) / 2048) for the two twists T = 1 (even outputs) and T = 5 (odd outputs)

@@ -527,6 +527,276 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// N = 2048 throughput kernel: one 512-thread workgroup = TWO gates (batches above one gate per CU).  The one-gate kernel above spends half
+// of every step pulling 768 KiB of key spectra (l = 3) through the CU's vector-memory path; here every key chunk multiplies the digit
+// spectra of two gates.  Two accumulators (64 KiB) leave 96 KiB for spectra -- the 2 x 2l HALF spectra of one twist -- so a step runs as
+// two half passes: forward transforms of the even-output halves (twist 1) of all rows of both gates, multiply into S0, the same for the
+// odd-output halves (twist 5, digits extracted again: the accumulators do not change inside a step) into S1, then the four inverse
+// transforms, the radix-2 merge and the integer atomics.  Transforms are the "qs" form of the twisted halves (no T1 tables in LDS, one
+// LDS crossing); the barriers wait for the LDS only (vmcnt(16)), so the two key chunks a wave has requested stay in flight across them:
+// the key stream never stops at a phase boundary.  LDS at l = 3: 64 + 96 = 160 KiB.
+// ------------------------------------------------------------------------------------------------------
+template <int VM>
+__device__ __forceinline__ void lds_barrier() {   // workgroup barrier that orders LDS traffic and leaves up to VM vector-memory loads in flight
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+}
+struct P2KDigits {
+    int parts, pw, L, Bgbit;
+    uint64_t offset;
+};
+// Digits of a step, computed ONCE for both half passes and all levels:
+//   stage   every wave takes half of one (gate, accumulator polynomial): t = top 32 bits of (X^a acc - acc) + offset for 16 coefficients per
+//           lane -> 8 KiB of 32-bit words per (gate, polynomial) in the spectrum area (slots 0..3, free at this point);
+//   pack    task f = (gate f / ROWS, digit row f % ROWS) reads the 32 words of the coefficients its lane transforms, cuts out its digit
+//           (level, part) and keeps the four digits of a radix-2 group as 16-bit fields of two registers: 16 VGPRs per task carry the
+//           digits through both half passes (the rotated 64-bit reads + offset + decomposition cost more than a half transform).
+__device__ __forceinline__ void p2k_stage(int wave, int lane, const int64_t (*sAcc)[4096], uint32_t *stage, int ai0, int ai1, uint64_t offset) {
+    const int gj = wave >> 1, g = gj >> 1, j = gj & 1;
+    const int ai = g ? ai1 : ai0;
+    if (ai == 0) return;
+    const int a2n = ai & 4095;
+    const int64_t *ap = sAcc[g] + j * 2048;
+    uint32_t *dst = stage + gj * 2048;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int c = (wave & 1) * 1024 + lane + 64 * k;
+        dst[c] = (uint32_t)((rot_minus_self64_n<2048>(ap, c, a2n) + offset) >> 32);
+    }
+}
+template <int LE>
+__device__ __forceinline__ void p2k_pack(int f, int lane, const uint32_t *stage, const P2KDigits &dg, uint32_t (&pk)[8][2]) {
+    constexpr int ROWS = 2 * LE;
+    const int g = f / ROWS, r = f % ROWS;
+    const uint32_t *src = stage + (g * 2 + r / LE) * 2048;
+    const int level = (r % LE) / dg.parts, part = (r % LE) % dg.parts;   // uniform per wave
+    const int shift = 32 - (level + 1) * dg.Bgbit;
+    const uint32_t mask = (1u << dg.Bgbit) - 1u;
+    const int32_t half = 1 << (dg.Bgbit - 1);
+    const int pw = dg.pw;
+    const int32_t hp = pw ? 1 << (pw - 1) : 0, mp = (1 << pw) - 1;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        int32_t d[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t t = src[lane + 64 * m + 512 * q];
+            int32_t v = (int32_t)((t >> shift) & mask) - half;      // decompose, J/tgsw.jl:112-138
+            if (dg.parts > 1) {                                       // balanced parts, least significant first
+                for (int w = 0; w < part; w++) v = (v - (((v + hp) & mp) - hp)) >> pw;
+                if (part < dg.parts - 1) v = ((v + hp) & mp) - hp;
+            }
+            d[q] = v;
+        }
+        pk[m][0] = ((uint32_t)d[0] & 0xffffu) | ((uint32_t)d[1] << 16);
+        pk[m][1] = ((uint32_t)d[2] & 0xffffu) | ((uint32_t)d[3] << 16);
+    }
+}
+// forward half transform of task f (slot f) from its packed digits
+template <int HALF>
+__device__ __forceinline__ void p2k_transform(int f, int lane, cplx *sSpec, const uint32_t (&pk)[8][2], const LaneRoots &roots, const W64 &w64) {
+    constexpr double R = 0.70710678118654752440;
+    cplx y[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const double d0 = (double)((int32_t)(pk[m][0] << 16) >> 16), d1 = (double)((int32_t)pk[m][0] >> 16);
+        const double d2 = (double)((int32_t)(pk[m][1] << 16) >> 16), d3 = (double)((int32_t)pk[m][1] >> 16);
+        // split2048 of z[m] = (d0, d2), z[m + 8] = (d1, d3): y = z[m] +- e^{i pi/4} z[m + 8]
+        const cplx w{(d1 - d3) * R, (d1 + d3) * R};
+        y[m] = HALF == 0 ? cplx{d0 + w.re, d2 + w.im} : cplx{d0 - w.re, d2 - w.im};
+    }
+    cplx *slot = sSpec + f * 512;   // the transpose runs inside the task's own, not yet published, spectrum slot
+    wave_fft_fwd_tq<HALF == 0 ? 1 : 5>(opaque_lane(lane), y, slot, LaneRoots{opaque_cplx(roots.b), opaque_cplx(roots.s)}, w64);
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) slot[m * 64 + lane] = y[m];
+}
+
+template <int LE>
+__global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs a) {
+    constexpr int ROWS = 2 * LE;
+    constexpr int TASKS = 2 * ROWS;
+    constexpr int SLOTS = TASKS > 8 ? TASKS : 8;
+    constexpr int PRE = 2;   // key chunks in flight per wave (32 VGPRs each); S0 / S1 of both gates hold 128
+    __shared__ int64_t sAcc[2][4096];
+    __shared__ cplx sSpec[SLOTS * 512];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // per-lane transform constants are phase-local: fetched again (L1 / L2 hits) at the start of every transform phase instead of living in
+    // 16 VGPRs across the multiply phases, where the four partial spectra, two key chunks and a digit spectrum leave no room (the allocator
+    // spilled them to scratch and reloaded them in front of every use)
+    auto tw_w64 = [&](int ln) { return W64{a.tw[1024 + 1 * 8 + (ln & 7)]}; };
+    auto tw_roots1 = [&](int ln) { return LaneRoots{a.tw[ln], a.tw[1216 + ln]}; };         // b_T = T1_T[0][lane], ratio
+    auto tw_roots5 = [&](int ln) { return LaneRoots{a.tw[512 + ln], a.tw[1216 + ln]}; };
+    P2KDigits dg;
+    dg.parts = a.parts > 1 ? a.parts : 1;
+    dg.pw = a.pw;
+    dg.L = LE / dg.parts;
+    dg.Bgbit = a.Bgbit;
+    dg.offset = decomp_offset64(dg.L, a.Bgbit);
+    const long job0 = 2 * (long)blockIdx.x;
+    const bool has1 = job0 + 1 < a.jobs;
+    const int32_t *bara0 = a.bara + job0 * a.w_pad;
+    const int32_t *bara1 = bara0 + (has1 ? a.w_pad : 0);
+    if (a.acc_in) {
+        for (int q = threadIdx.x; q < 8192; q += 512) {
+            const int g = q >> 12;
+            if (g == 0 || has1) sAcc[g][q & 4095] = a.acc_in[(job0 + g) * 4096 + (q & 4095)];
+        }
+    } else if (wave < 2 && (wave == 0 || has1)) {
+        acc_init_64_n<2048>(lane, sAcc[wave], sAcc[wave] + 2048, a.barb[job0 + wave], a.mu);
+    }
+    __syncthreads();
+    const int o = wave >> 2, h = wave & 3;
+    auto chunk = [&](int step, int r, int half) { return a.bk + mk_chunk_index_2k(step, r, h, o, ROWS) * 512 + half * 512; };
+    auto active = [&](int i) { return bara0[i] != 0 || (has1 && bara1[i] != 0); };   // uniform over the workgroup
+    int i = 0;
+    while (i < a.pn && !active(i)) i++;
+    STAMP_DECL;
+    while (i < a.pn) {
+        const int ai0 = bara0[i], ai1 = has1 ? bara1[i] : 0;
+        int inext = i + 1;
+        while (inext < a.pn && !active(inext)) inext++;
+        // ---- digits of the step
+        const bool t0 = wave < TASKS && ((wave / ROWS) ? ai1 : ai0) != 0;                  // this wave's first / second forward task is live
+        const bool t1 = wave + 8 < TASKS && (((wave + 8) / ROWS) ? ai1 : ai0) != 0;
+        uint32_t pk0[8][2], pk1[8][2];
+        p2k_stage(wave, lane, sAcc, reinterpret_cast<uint32_t *>(sSpec), ai0, ai1, dg.offset);
+        lds_barrier<8 * PRE>();
+        if (t0) p2k_pack<LE>(wave, lane, reinterpret_cast<const uint32_t *>(sSpec), dg, pk0);
+        if (t1) p2k_pack<LE>(wave + 8, lane, reinterpret_cast<const uint32_t *>(sSpec), dg, pk1);
+        lds_barrier<8 * PRE>();   // staged words consumed: the slots are free for the spectra
+        // ---- half pass 0: even outputs (twist 1)
+        if (t0 || t1) {
+            const int ln = opaque_lane(lane);
+            const W64 w64 = tw_w64(ln);
+            const LaneRoots roots1 = tw_roots1(ln);
+            if (t0) p2k_transform<0>(wave, lane, sSpec, pk0, roots1, w64);
+            if (t1) p2k_transform<0>(wave + 8, lane, sSpec, pk1, roots1, w64);
+        }
+        cplx B[PRE][8];
+        mk_pin();
+#pragma unroll
+        for (int r = 0; r < PRE; r++) load8(lane, B[r], chunk(i, r, 0));
+        mk_pin();
+        STAMP(0);
+        lds_barrier<8 * PRE>();   // spectra published
+        STAMP(1);
+        cplx S0a[8], S0b[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) S0a[m] = S0b[m] = cplx{0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            cplx z[8];
+            if (ai0 != 0) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) z[m] = sSpec[r * 512 + m * 64 + lane];
+                mac8r(S0a, z, B[r % PRE]);
+            }
+            if (ai1 != 0) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) z[m] = sSpec[(ROWS + r) * 512 + m * 64 + lane];
+                mac8r(S0b, z, B[r % PRE]);
+            }
+            mk_pin();
+            if (r + PRE < ROWS) load8(lane, B[r % PRE], chunk(i, r + PRE, 0));
+            mk_pin();
+        }
+        STAMP(2);
+        lds_barrier<8 * PRE>();   // spectra consumed
+        STAMP(4);
+        // ---- half pass 1: odd outputs (twist 5), same digits
+        if (t0 || t1) {
+            const int ln = opaque_lane(lane);
+            const W64 w64 = tw_w64(ln);
+            const LaneRoots roots5 = tw_roots5(ln);
+            if (t0) p2k_transform<1>(wave, lane, sSpec, pk0, roots5, w64);
+            if (t1) p2k_transform<1>(wave + 8, lane, sSpec, pk1, roots5, w64);
+        }
+        mk_pin();
+#pragma unroll
+        for (int r = 0; r < PRE; r++) load8(lane, B[r], chunk(i, r, 1));
+        mk_pin();
+        STAMP(0);
+        lds_barrier<8 * PRE>();
+        STAMP(1);
+        cplx S1a[8], S1b[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) S1a[m] = S1b[m] = cplx{0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            cplx z[8];
+            if (ai0 != 0) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) z[m] = sSpec[r * 512 + m * 64 + lane];
+                mac8r(S1a, z, B[r % PRE]);
+            }
+            if (ai1 != 0) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) z[m] = sSpec[(ROWS + r) * 512 + m * 64 + lane];
+                mac8r(S1b, z, B[r % PRE]);
+            }
+            mk_pin();
+            if (r + PRE < ROWS) load8(lane, B[r % PRE], chunk(i, r + PRE, 1));
+            mk_pin();
+        }
+        STAMP(2);
+        lds_barrier<8 * PRE>();   // spectra consumed: the area is transpose scratch from here on; every rotated read of the accumulators is done
+        STAMP(4);
+        // ---- inverse transforms, merge, accumulate
+        {
+            cplx *xb = sSpec + wave * 512;
+            const int ln = opaque_lane(lane);
+            const W64 w64 = tw_w64(ln);
+            const LaneRoots roots1 = tw_roots1(ln), roots5 = tw_roots5(ln);
+            if (ai0 != 0) {
+                unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[0]) + o * 2048;
+                wave_fft_inv_tq<1>(ln, S0a, xb, LaneRoots{opaque_cplx(roots1.b), opaque_cplx(roots1.s)}, w64);
+                wave_fft_inv_tq<5>(ln, S1a, xb, LaneRoots{opaque_cplx(roots5.b), opaque_cplx(roots5.s)}, w64);
+                cplx lo[8], hi[8];
+                merge2048(S0a, S1a, lo, hi);
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const int q = lane + 64 * m;
+                    atomicAdd(accu + q, (unsigned long long)round_i64(lo[m].re) << (16 * h));
+                    atomicAdd(accu + q + 512, (unsigned long long)round_i64(hi[m].re) << (16 * h));
+                    atomicAdd(accu + q + 1024, (unsigned long long)round_i64(lo[m].im) << (16 * h));
+                    atomicAdd(accu + q + 1536, (unsigned long long)round_i64(hi[m].im) << (16 * h));
+                }
+            }
+            if (ai1 != 0) {
+                unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[1]) + o * 2048;
+                wave_fft_inv_tq<1>(ln, S0b, xb, LaneRoots{opaque_cplx(roots1.b), opaque_cplx(roots1.s)}, w64);
+                wave_fft_inv_tq<5>(ln, S1b, xb, LaneRoots{opaque_cplx(roots5.b), opaque_cplx(roots5.s)}, w64);
+                cplx lo[8], hi[8];
+                merge2048(S0b, S1b, lo, hi);
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const int q = lane + 64 * m;
+                    atomicAdd(accu + q, (unsigned long long)round_i64(lo[m].re) << (16 * h));
+                    atomicAdd(accu + q + 512, (unsigned long long)round_i64(hi[m].re) << (16 * h));
+                    atomicAdd(accu + q + 1024, (unsigned long long)round_i64(lo[m].im) << (16 * h));
+                    atomicAdd(accu + q + 1536, (unsigned long long)round_i64(hi[m].im) << (16 * h));
+                }
+            }
+        }
+        STAMP(3);
+        lds_barrier<8 * PRE>();   // accumulators updated and scratch free before the next step
+        STAMP(5);
+        i = inext;
+    }
+    STAMP_FLUSH(blockIdx.x, wave);
+    __syncthreads();
+    if (a.acc_out) {
+        for (int q = threadIdx.x; q < 8192; q += 512) {
+            const int g = q >> 12;
+            if (g == 0 || has1) a.acc_out[(job0 + g) * 4096 + (q & 4095)] = sAcc[g][q & 4095];
+        }
+    } else if (wave < 2 && (wave == 0 || has1)) {
+        extract_64_n<2048>(lane, sAcc[wave], sAcc[wave] + 2048, a.out + (job0 + wave) * 2049);
+    }
+}
+
 // the batched N = 2048 rotation (any number of row parts, two-part digits) shared with the KMS scheme
 #include "thfhe_rot2k.h"
 
@@ -678,6 +948,17 @@ int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a) {
         MKBRArgs b = a;
         b.parts = c->parts;
         b.pw = c->pw;
+        if (a.jobs > c->pair_threshold) {   // more gates than CUs: two gates per workgroup share every key chunk
+            const dim3 pgrid((unsigned)((a.jobs + 1) / 2));
+            switch (c->p.l * c->parts) {
+            case 1: hipLaunchKernelGGL(mk_blind_rotate_pair2k_kernel<1>, pgrid, block, 0, c->stream, b); break;
+            case 2: hipLaunchKernelGGL(mk_blind_rotate_pair2k_kernel<2>, pgrid, block, 0, c->stream, b); break;
+            case 3: hipLaunchKernelGGL(mk_blind_rotate_pair2k_kernel<3>, pgrid, block, 0, c->stream, b); break;
+            default: return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 2048 needs l x digit parts <= 3");
+            }
+            THFHE_HIP(hipGetLastError());
+            return THFHE_OK;
+        }
         switch (c->p.l * c->parts) {
         case 1: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<1>, grid, block, 0, c->stream, b); break;
         case 2: hipLaunchKernelGGL(mk_blind_rotate_coop2k_kernel<2>, grid, block, 0, c->stream, b); break;
@@ -825,7 +1106,8 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto &e : c->ev) CK(hipEventCreate(&e));
-    std::vector<cplx> tw(1088 + 128);  // N = 1024: T1[512] T2[64]; N = 2048: T1(twist 1)[512] T1(twist 5)[512] T2[64]; [1088..): per-lane roots (N = 1024)
+    std::vector<cplx> tw(1088 + 128 + 64);  // N = 1024: T1[512] T2[64]; N = 2048: T1(twist 1)[512] T1(twist 5)[512] T2[64]; [1088..): per-lane roots (N = 1024); [1216..): pass-1 ratio (N = 2048)
+    make_lane_ratio_2048(tw.data() + 1216);
     if (p->N == 2048) {
         std::vector<cplx> unused(512);
         make_twiddles_2048(tw.data(), tw.data() + 512);

@@ -536,7 +536,10 @@ class MKCloudKey:
         p = self.params
         if p.N == 2048:
             le = p.l * (((p.Bgbit + 8) // 9) if p.Bgbit > 10 else 1)
-            return "kms_tlev_rotate_kernel" if le > 3 else f"mk_blind_rotate_coop2k_kernel<{le}>"
+            if le > 3:
+                return "kms_tlev_rotate_kernel"
+            pair = rotations > getattr(self, "_pair_threshold", 256)
+            return f"mk_blind_rotate_{'pair2k' if pair else 'coop2k'}_kernel<{le}>"
         pair = p.l <= 3 and rotations > getattr(self, "_pair_threshold", 256)
         return f"mk_blind_rotate_{'pair' if pair else 'coop'}_kernel<{p.l}>"
 
