@@ -666,7 +666,12 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
         if (t0) p2k_pack<LE>(wave, lane, reinterpret_cast<const uint32_t *>(sSpec), dg, pk0);
         if (t1) p2k_pack<LE>(wave + 8, lane, reinterpret_cast<const uint32_t *>(sSpec), dg, pk1);
         lds_barrier<8 * PRE>();   // staged words consumed: the slots are free for the spectra
-        // ---- half pass 0: even outputs (twist 1)
+        // ---- half pass 0: even outputs (twist 1); its first key chunks are requested ahead of the transforms (no partial spectra alive yet)
+        cplx B[PRE][8];
+        mk_pin();
+#pragma unroll
+        for (int r = 0; r < PRE; r++) load8(lane, B[r], chunk(i, r, 0));
+        mk_pin();
         if (t0 || t1) {
             const int ln = opaque_lane(lane);
             const W64 w64 = tw_w64(ln);
@@ -674,11 +679,6 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
             if (t0) p2k_transform<0>(wave, lane, sSpec, pk0, roots1, w64);
             if (t1) p2k_transform<0>(wave + 8, lane, sSpec, pk1, roots1, w64);
         }
-        cplx B[PRE][8];
-        mk_pin();
-#pragma unroll
-        for (int r = 0; r < PRE; r++) load8(lane, B[r], chunk(i, r, 0));
-        mk_pin();
         STAMP(0);
         lds_barrier<8 * PRE>();   // spectra published
         STAMP(1);
