@@ -128,7 +128,7 @@ int thfhe_mk_gates(thfhe_mk_ctx *ctx, int op, const int32_t *in0, const int32_t 
 /* one launch for a DAG level of two-input 3-gen gates (NAND / OR / AND / XOR), per-gate opcodes in the HOST array ops */
 int thfhe_mk_gates_mixed(thfhe_mk_ctx *ctx, const int32_t *ops, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count);
 /* Batches of at most `max_single_jobs` rotations run one gate per workgroup (latency), larger ones two gates per workgroup sharing
- * every key chunk (throughput; N = 1024, l <= 3).  Default 256 = one workgroup per CU of an MI355X. */
+ * every key chunk (throughput; l <= 3 on the ring of degree 1024, every set on the ring of degree 2048).  Default 256 = one workgroup per CU of an MI355X. */
 int thfhe_mk_set_pair_threshold(thfhe_mk_ctx *ctx, long max_single_jobs);
 /* Gate-DAG evaluation for the 3-gen scheme (same contract as thfhe_dag_run; records of P*n+1 words): the reference's multi-key integer
  * circuits mk_add_3gen ... mk_int_mul_3gen (J/3gen_mk_gates.jl:183-362).  Opcodes: NAND / OR / AND / XOR, AND3, MUX, NOT, COPY. */
@@ -264,6 +264,9 @@ int thfhe_kms_rotate_parties_dev(thfhe_kms_ctx *ctx, int op, const int32_t *d_x,
                                  size_t count);
 int thfhe_kms_finish_dev(thfhe_kms_ctx *ctx, int op, const int32_t *d_x, const int32_t *d_y, const int64_t *d_lev_all, int32_t *d_out, size_t count);
 int thfhe_kms_set_stream(thfhe_kms_ctx *ctx, void *hip_stream);
+/* Launches of at most `max_single_jobs` TLev / RLWE rotations run one job per workgroup, larger ones two jobs per workgroup that share
+ * every key chunk (kms_tlev_rotate_pair_kernel).  Default 256 = one workgroup per CU of an MI355X. */
+int thfhe_kms_set_pair_threshold(thfhe_kms_ctx *ctx, long max_single_jobs);
 
 #ifdef __cplusplus
 }

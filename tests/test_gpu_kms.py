@@ -119,3 +119,38 @@ def test_kms4_moderate_size_buffers_regrow_between_routes(O):
         assert np.array_equal(u[g], orc.bootstrap_wo_keyswitch(ca[g])), g
     assert np.array_equal(ck.gates(O.XOR, ca[:9], cb[:9])[[2, 8]], orc.gates(O.XOR, ca[[2, 8]], cb[[2, 8]]))   # shrinks again
     ck.close()
+
+
+@pytest.mark.parametrize("name,n,parties", [("KMS2", 12, None), ("KMS4", 6, None), ("KMS8", 4, 3), ("KMS32", 3, 2)])
+def test_kms_two_jobs_per_workgroup_bit_exact(O, name, n, parties):
+    # kms_tlev_rotate_pair_kernel (two jobs share every key chunk; row parts in batches of six with the partial spectra parked in between):
+    # forced for small batches.  KMS2: 12 row parts, l_lev = 2 (the two TLev samples of a gate form a pair); KMS4: 10 row parts; KMS8: 16 row
+    # parts in three batches, l_lev = 3 (pairs straddle gates: different rotations in one workgroup); KMS32: l_lev = 7, odd job counts.
+    # Against the oracle and against the one-job kernel, incl. zero mask words in one job of a pair and the RLWE rotation of fast_boot.
+    from thfhe import kms
+    p, K, orc, ck = setup(O, name, n, parties)
+    a, b = np.array([0, 0, 1, 1, 1]), np.array([0, 1, 0, 1, 1])
+    ca, cb = K.encrypt(a, 21), K.encrypt(b, 22)
+    ca[1, 2] = cb[1, 2] = 0
+    ca[4, n + 1] = cb[4, n + 1] = 0
+    bar = kms.modswitch(ca, p.N)
+    single_lev = [ck.tlev_rotate(party, bar[:3, party * n:(party + 1) * n]) for party in range(p.parties)]
+    single_gate = kms.mk_gate_nand_new(ck, ca, cb)
+    rng = np.random.default_rng(3)
+    acc1 = rng.integers(-2**63, 2**63, size=(3, 2, p.N), dtype=np.int64)
+    single_rot = ck.rlwe_rotate(0, bar[:3, :n], acc1)
+    ck.set_pair_threshold(0)
+    for party in range(p.parties):
+        lev = ck.tlev_rotate(party, bar[:3, party * n:(party + 1) * n])
+        assert np.array_equal(lev, single_lev[party]), (name, party)
+        for g in range(3):
+            assert np.array_equal(lev[g], orc.tlev_rotate(party, bar[g, party * n:(party + 1) * n])), (name, party, g)
+    assert np.array_equal(ck.rlwe_rotate(0, bar[:3, :n], acc1), single_rot)
+    out = kms.mk_gate_nand_new(ck, ca, cb)
+    assert np.array_equal(out, single_gate)
+    assert np.array_equal(out, orc.gates(O.NAND, ca, cb))
+    fast = kms.mk_gate_nand_new(ck, ca, cb, fast_boot=True)
+    assert np.array_equal(fast, orc.gates(O.NAND, ca, cb, fast_boot=True))
+    fa, fb = K.encrypt(a, 23), K.encrypt(b, 24)
+    assert np.array_equal(K.decrypt(kms.mk_gate_nand_new(ck, fa, fb)), ~(a.astype(bool) & b.astype(bool)))
+    ck.close()

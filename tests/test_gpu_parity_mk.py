@@ -176,6 +176,11 @@ def test_mk256_two_level_wide_base_gadget_bit_exact(O, n, parties):
     assert np.array_equal(K.decrypt_bits(ck.gates(thfhe.NAND, ca, cb)), ~(a.astype(bool) & b.astype(bool)))
     ref = np.stack([orc.keyswitch(orc.bootstrap_wo_keyswitch(r)) for r in ca[:2]])
     assert np.array_equal(thfhe.mk_bootstrap_3gen(ck, thfhe.MU8_64, ca[:2]), ref)
+    # the same through two jobs per workgroup (kms_tlev_rotate_pair_kernel: eight row parts = two batches, partial spectra parked in between)
+    ck.set_pair_threshold(0)
+    assert ck.rotation_kernel_name(4) == "kms_tlev_rotate_pair_kernel"
+    for op, args in ((O.NAND, (ca, cb)), (O.AND3, (ca, cb, cc)), (O.MUX, (ca, cb, cc))):
+        assert np.array_equal(ck.gates(op, *args), orc.gates(op, *args)), op
     ck.close()
 
 

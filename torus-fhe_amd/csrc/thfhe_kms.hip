@@ -123,6 +123,8 @@ struct thfhe_kms_ctx {
     hipStream_t stream = nullptr;      // the stream every call enqueues on
     hipStream_t own_stream = nullptr;  // created with the context; `stream` differs only after thfhe_kms_set_stream
     cplx *d_tw = nullptr;
+    Rot2kPark park;              // two jobs per workgroup: partial spectra between row-part batches (thfhe_rot2k.h)
+    long pair_threshold = 256;   // launches of more TLev / RLWE rotations than this (one per CU) run two jobs per workgroup
     cplx *d_bk = nullptr;       // [party][j][row part][o][h][half][512]
     int32_t *d_ksk = nullptr;
     int parts = 1, lo_bits = 1, row_words = 0;
@@ -206,7 +208,8 @@ int thfhe_kms_ctx_create(const thfhe_kms_params *p, const int64_t *gsw, const in
     } while (0)
     CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    std::vector<cplx> tw(1088), unused(512);
+    std::vector<cplx> tw(1216 + 64), unused(512);   // T1 (twist 1), T1 (twist 5), T2; [1216..): pass-1 ratio of the table-free transforms
+    make_lane_ratio_2048(tw.data() + 1216);
     make_twiddles_2048(tw.data(), tw.data() + 512);
     make_twiddles_1024(unused.data(), tw.data() + 1024);
     CK(hipMalloc(&c->d_tw, tw.size() * sizeof(cplx)));
@@ -253,6 +256,7 @@ void thfhe_kms_ctx_destroy(thfhe_kms_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     (void)hipFree(c->d_tw);
+    (void)hipFree(c->park.buf);
     (void)hipFree(c->d_bk);
     (void)hipFree(c->d_ksk);
     for (auto &q : c->d_buf) (void)hipFree(q);
@@ -277,8 +281,10 @@ int thfhe_kms_tlev_rotate(thfhe_kms_ctx *c, int party, const int32_t *bara, int6
     THFHE_HIP(hipMemcpyAsync(c->d_buf[0], bara, count * c->p.n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     KmsBRArgs a{c->d_bk + (size_t)party * c->party_stride, c->d_tw, (const int32_t *)c->d_buf[0], (int64_t *)c->d_buf[1], nullptr, (long)jobs,
                 c->p.n, c->p.l_gsw, c->p.bg_gsw, c->parts, c->lo_bits, c->p.l_lev, c->p.bg_lev, c->p.n};
-    hipLaunchKernelGGL(kms_tlev_rotate_kernel, dim3((unsigned)jobs), dim3(512), 0, c->stream, a);
-    THFHE_HIP(hipGetLastError());
+    {
+        int rc2 = rot2k_launch(a, c->stream, c->pair_threshold, c->park);
+        if (rc2) return rc2;
+    }
     THFHE_HIP(hipMemcpyAsync(lev, c->d_buf[1], jobs * 4096 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     THFHE_HIP(hipStreamSynchronize(c->stream));
     return THFHE_OK;
@@ -297,8 +303,10 @@ int thfhe_kms_rlwe_rotate(thfhe_kms_ctx *c, int party, const int32_t *bara, int6
     THFHE_HIP(hipMemcpyAsync(c->d_buf[1], acc, count * 4096 * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     KmsBRArgs a{c->d_bk + (size_t)party * c->party_stride, c->d_tw, (const int32_t *)c->d_buf[0], (int64_t *)c->d_buf[1], (const int64_t *)c->d_buf[1],
                 (long)count, c->p.n, c->p.l_gsw, c->p.bg_gsw, c->parts, c->lo_bits, 1, c->p.bg_lev, c->p.n};   // in place: a workgroup reads its sample before it writes it
-    hipLaunchKernelGGL(kms_tlev_rotate_kernel, dim3((unsigned)count), dim3(512), 0, c->stream, a);
-    THFHE_HIP(hipGetLastError());
+    {
+        int rc2 = rot2k_launch(a, c->stream, c->pair_threshold, c->park);
+        if (rc2) return rc2;
+    }
     THFHE_HIP(hipMemcpyAsync(acc, c->d_buf[1], count * 4096 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     THFHE_HIP(hipStreamSynchronize(c->stream));
     return THFHE_OK;
@@ -488,9 +496,7 @@ int kms_lev_rlwe_mul_dev(thfhe_kms_ctx *c, KmsTables &tabs, int party, size_t G,
 int kms_launch_rotation(thfhe_kms_ctx *c, int party, const int32_t *d_bara, int64_t *d_out, const int64_t *d_in, size_t gates, int l_lev) {
     KmsBRArgs a{c->d_bk + (size_t)party * c->party_stride, c->d_tw, d_bara, d_out, d_in, (long)(gates * l_lev),
                 c->p.n, c->p.l_gsw, c->p.bg_gsw, c->parts, c->lo_bits, l_lev, c->p.bg_lev, c->p.n};
-    hipLaunchKernelGGL(kms_tlev_rotate_kernel, dim3((unsigned)(gates * l_lev)), dim3(512), 0, c->stream, a);
-    THFHE_HIP(hipGetLastError());
-    return THFHE_OK;
+    return rot2k_launch(a, c->stream, c->pair_threshold, c->park);
 }
 int kms_finish(thfhe_kms_ctx *c) {
     int flag = 0;
@@ -727,6 +733,15 @@ int thfhe_kms_set_stream(thfhe_kms_ctx *c, void *hip_stream) {
     std::lock_guard<std::mutex> g(c->mu);
     THFHE_HIP(hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return THFHE_OK;
+}
+
+// Launches of at most `max_single_jobs` rotations run one job per workgroup, larger ones two jobs per workgroup sharing every key chunk.
+int thfhe_kms_set_pair_threshold(thfhe_kms_ctx *c, long max_single_jobs) {
+    if (!c) return thfhe_fail(THFHE_E_INVALID, "null ctx");
+    if (max_single_jobs < 0) return thfhe_fail(THFHE_E_INVALID, "threshold must be >= 0");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->pair_threshold = max_single_jobs;
     return THFHE_OK;
 }
 

@@ -527,6 +527,9 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
     }
 }
 
+// the batched N = 2048 rotation (any number of row parts, two-part digits) shared with the KMS scheme
+#include "thfhe_rot2k.h"
+
 // ------------------------------------------------------------------------------------------------------
 // N = 2048 throughput kernel: one 512-thread workgroup = TWO gates (batches above one gate per CU).  The one-gate kernel above spends half
 // of every step pulling 768 KiB of key spectra (l = 3) through the CU's vector-memory path; here every key chunk multiplies the digit
@@ -537,10 +540,6 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
 // LDS crossing); the barriers wait for the LDS only (vmcnt(16)), so the two key chunks a wave has requested stay in flight across them:
 // the key stream never stops at a phase boundary.  LDS at l = 3: 64 + 96 = 160 KiB.
 // ------------------------------------------------------------------------------------------------------
-template <int VM>
-__device__ __forceinline__ void lds_barrier() {   // workgroup barrier that orders LDS traffic and leaves up to VM vector-memory loads in flight
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
-}
 struct P2KDigits {
     int parts, pw, L, Bgbit;
     uint64_t offset;
@@ -592,26 +591,6 @@ __device__ __forceinline__ void p2k_pack(int f, int lane, const uint32_t *stage,
         pk[m][1] = ((uint32_t)d[2] & 0xffffu) | ((uint32_t)d[3] << 16);
     }
 }
-// forward half transform of task f (slot f) from its packed digits
-template <int HALF>
-__device__ __forceinline__ void p2k_transform(int f, int lane, cplx *sSpec, const uint32_t (&pk)[8][2], const LaneRoots &roots, const W64 &w64) {
-    constexpr double R = 0.70710678118654752440;
-    cplx y[8];
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-        const double d0 = (double)((int32_t)(pk[m][0] << 16) >> 16), d1 = (double)((int32_t)pk[m][0] >> 16);
-        const double d2 = (double)((int32_t)(pk[m][1] << 16) >> 16), d3 = (double)((int32_t)pk[m][1] >> 16);
-        // split2048 of z[m] = (d0, d2), z[m + 8] = (d1, d3): y = z[m] +- e^{i pi/4} z[m + 8]
-        const cplx w{(d1 - d3) * R, (d1 + d3) * R};
-        y[m] = HALF == 0 ? cplx{d0 + w.re, d2 + w.im} : cplx{d0 - w.re, d2 - w.im};
-    }
-    cplx *slot = sSpec + f * 512;   // the transpose runs inside the task's own, not yet published, spectrum slot
-    wave_fft_fwd_tq<HALF == 0 ? 1 : 5>(opaque_lane(lane), y, slot, LaneRoots{opaque_cplx(roots.b), opaque_cplx(roots.s)}, w64);
-    wave_sync();
-#pragma unroll
-    for (int m = 0; m < 8; m++) slot[m * 64 + lane] = y[m];
-}
-
 template <int LE>
 __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs a) {
     constexpr int ROWS = 2 * LE;
@@ -676,8 +655,8 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
             const int ln = opaque_lane(lane);
             const W64 w64 = tw_w64(ln);
             const LaneRoots roots1 = tw_roots1(ln);
-            if (t0) p2k_transform<0>(wave, lane, sSpec, pk0, roots1, w64);
-            if (t1) p2k_transform<0>(wave + 8, lane, sSpec, pk1, roots1, w64);
+            if (t0) r2k_transform<0>(wave, lane, sSpec, pk0, roots1, w64);
+            if (t1) r2k_transform<0>(wave + 8, lane, sSpec, pk1, roots1, w64);
         }
         STAMP(0);
         lds_barrier<8 * PRE>();   // spectra published
@@ -710,8 +689,8 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
             const int ln = opaque_lane(lane);
             const W64 w64 = tw_w64(ln);
             const LaneRoots roots5 = tw_roots5(ln);
-            if (t0) p2k_transform<1>(wave, lane, sSpec, pk0, roots5, w64);
-            if (t1) p2k_transform<1>(wave + 8, lane, sSpec, pk1, roots5, w64);
+            if (t0) r2k_transform<1>(wave, lane, sSpec, pk0, roots5, w64);
+            if (t1) r2k_transform<1>(wave + 8, lane, sSpec, pk1, roots5, w64);
         }
         mk_pin();
 #pragma unroll
@@ -797,8 +776,6 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
     }
 }
 
-// the batched N = 2048 rotation (any number of row parts, two-part digits) shared with the KMS scheme
-#include "thfhe_rot2k.h"
 
 // initial accumulator of the batched path, in global memory: acc = (0, X^{-barb} * (mu, ..., mu))   (J/3gen_mk_internals.jl:91-92)
 __global__ __launch_bounds__(256) void mk_acc_init_2k_kernel(const int32_t *__restrict__ barb, int64_t mu, long jobs, int64_t *__restrict__ acc) {
@@ -845,6 +822,7 @@ struct thfhe_mk_ctx {
     int32_t *d_ksk = nullptr;
     cplx *d_tw = nullptr;
     int row_words = 0, w_pad = 0, words = 0, log2_2n = 11;
+    Rot2kPark park;              // batched N = 2048 rotation, two jobs per workgroup: partial spectra between row-part batches
     long pair_threshold = 256;  // batches of more rotations than this run two gates per workgroup (mk_blind_rotate_pair_kernel)
     bool batched = false;       // N = 2048 with l x digit parts > 3: thfhe_rot2k.h (row parts through the LDS in batches), key table in its layout
     int64_t *d_acc = nullptr;   // batched path: accumulators in global memory, int64[jobs][2][2048]
@@ -939,7 +917,10 @@ int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a) {
         }
         if (!a.acc_in) hipLaunchKernelGGL(mk_acc_init_2k_kernel, dim3((unsigned)a.jobs), dim3(256), 0, c->stream, a.barb, a.mu, a.jobs, acc);
         KmsBRArgs k{c->d_bk, c->d_tw, a.bara, acc, a.acc_in ? a.acc_in : acc, a.jobs, a.pn, c->p.l, c->p.Bgbit, c->parts, c->pw, 1, 1, a.w_pad};
-        hipLaunchKernelGGL(kms_tlev_rotate_kernel, grid, block, 0, c->stream, k);
+        {
+            int rc = rot2k_launch(k, c->stream, c->pair_threshold, c->park);
+            if (rc) return rc;
+        }
         if (!a.acc_out) hipLaunchKernelGGL(mk_extract_kernel, grid, dim3(256), 0, c->stream, (const int64_t *)acc, a.out, a.jobs, 2048);
         THFHE_HIP(hipGetLastError());
         return THFHE_OK;
@@ -1068,7 +1049,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     const int pw = parts > 1 ? (p->Bgbit + parts - 1) / parts : 0;
     // l x parts <= 3: the one-pass N = 2048 kernel; more row parts (the 256-party set: l = 2, Bgbit = 18 -> 2 x 2 parts) go through the batched
     // rotation of thfhe_rot2k.h, which knows one- and two-part digits.  Exactness: 2 l parts N 2^(part bits - 1) 2^15 <= 2^37 (section 4.3).
-    const bool batched = p->N == 2048 && p->l * parts > 3;
+    const bool batched = p->N == 2048 && (p->l * parts > 3 || (parts <= 2 && getenv("THFHE_MK_FORCE_BATCHED") != nullptr));   // the switch: developer A/B of the two N = 2048 paths
     if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || (!batched && p->l * p->Bgbit > 32) || p->l * p->Bgbit > 64 || (parts > 1 && p->N != 2048) || (batched && parts > 2) ||
         (batched && (double)(2 * p->l * parts) * 2048.0 * (double)(1 << ((parts > 1 ? pw : p->Bgbit) - 1)) * 32768.0 > 137438953472.0))
         return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 4, l*Bgbit <= 32 (64 on the batched path), and Bgbit <= 10 (FP64 exactness bound) unless N = 2048 with l x ceil(Bgbit / 9) <= 3 or two-part digits");
@@ -1195,6 +1176,7 @@ void thfhe_mk_ctx_destroy(thfhe_mk_ctx *c) {
     (void)hipFree(c->d_bk);
     (void)hipFree(c->d_ksk);
     (void)hipFree(c->d_tw);
+    (void)hipFree(c->park.buf);
     (void)hipFree(c->d_bara);
     (void)hipFree(c->d_barb);
     (void)hipFree(c->d_u);

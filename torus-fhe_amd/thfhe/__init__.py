@@ -167,6 +167,7 @@ SIGNATURES = {
     "thfhe_kms_rotate_parties_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t]),
     "thfhe_kms_finish_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
     "thfhe_kms_set_stream": (C.c_int, [_vp, _vp]),
+    "thfhe_kms_set_pair_threshold": (C.c_int, [_vp, C.c_long]),
     "thfhe_kms_keyswitch": (C.c_int, [_vp, _i32p, _i32p, C.c_size_t]),
     "thfhe_pm_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "thfhe_pm_ctx_destroy": (None, [_vp]),
@@ -536,9 +537,9 @@ class MKCloudKey:
         p = self.params
         if p.N == 2048:
             le = p.l * (((p.Bgbit + 8) // 9) if p.Bgbit > 10 else 1)
-            if le > 3:
-                return "kms_tlev_rotate_kernel"
             pair = rotations > getattr(self, "_pair_threshold", 256)
+            if le > 3:
+                return "kms_tlev_rotate_pair_kernel" if pair else "kms_tlev_rotate_kernel"
             return f"mk_blind_rotate_{'pair2k' if pair else 'coop2k'}_kernel<{le}>"
         pair = p.l <= 3 and rotations > getattr(self, "_pair_threshold", 256)
         return f"mk_blind_rotate_{'pair' if pair else 'coop'}_kernel<{p.l}>"

@@ -65,6 +65,10 @@ class KMSCloudKey:
         except Exception:
             pass
 
+    def set_pair_threshold(self, max_single_jobs):
+        """Launches of <= max_single_jobs rotations run one job per workgroup; larger ones two jobs per workgroup (shared key chunks)."""
+        _check(lib().thfhe_kms_set_pair_threshold(self.h, int(max_single_jobs)))
+
     # ---- the pieces (same decomposition as the reference) --------------------------------------------------------------------------
     def tlev_rotate(self, party, bara):
         """mk_ith_blind_rotate for a batch: bara int32[count][n] -> int64[count][l_lev][2][N]."""
