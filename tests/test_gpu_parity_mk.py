@@ -239,6 +239,9 @@ def test_mk4_n2048_full_size(O):
     assert np.array_equal(got, orc.gates(O.NAND, ca, cb))      # all 96 gates against the MK oracle, bit for bit
     assert np.array_equal(K.decrypt_bits(got), ~(a.astype(bool) & b.astype(bool)))
     assert np.array_equal(got, ck.gates(thfhe.NAND, ca, cb))   # deterministic
+    ck.set_pair_threshold(0)                                     # the same 96 gates two per workgroup (mk_blind_rotate_pair2k_kernel) at full size
+    assert ck.rotation_kernel_name(B) == "mk_blind_rotate_pair2k_kernel<3>"
+    assert np.array_equal(got, ck.gates(thfhe.NAND, ca, cb))
     ck.close()
 
 

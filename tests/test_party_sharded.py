@@ -46,6 +46,8 @@ RANK_SCRIPT = """
     else:
         from thfhe.party_sharded import HipPartyBackend
         be = HipPartyBackend(tp, (first, last), K.bk[first:last], K.ksk[first:last], device=0)
+        if os.environ.get("THFHE_TEST_PAIR0"):   # two gates per workgroup even for this handful of gates
+            be.ck.set_pair_threshold(0)
         dev = "cuda:0"
     ev = PartyShardedEvaluator(tp, be, pipeline_chunks={chunks})
     G = {gates}
@@ -73,7 +75,7 @@ RANK_SCRIPT = """
 """
 
 
-def run_two_ranks(tmp_path, mode, over, gates, chunks, timeout, pset="MK2", world=2):
+def run_two_ranks(tmp_path, mode, over, gates, chunks, timeout, pset="MK2", world=2, extra_env=None):
     script = tmp_path / "rank.py"
     script.write_text(textwrap.dedent(RANK_SCRIPT.format(tests=os.path.join(ROOT, "tests"), pkg=os.path.join(ROOT, "torus-fhe_amd"),
                                                          mode=mode, over=over, gates=gates, chunks=chunks, pset=pset)))
@@ -81,7 +83,7 @@ def run_two_ranks(tmp_path, mode, over, gates, chunks, timeout, pset="MK2", worl
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2")
+                   OMP_NUM_THREADS="2", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for pr in procs:
@@ -133,5 +135,14 @@ def test_party_topology():
 @pytest.mark.gpu
 def test_party_sharded_two_ranks_one_gpu_bit_exact(tmp_path):
     outs = run_two_ranks(tmp_path, "hip", dict(), gates=6, chunks=3, timeout=900)
+    for o in outs:
+        assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt", "replica")), o
+
+
+@pytest.mark.gpu
+def test_party_sharded_n2048_two_gates_per_workgroup(tmp_path):
+    # the accumulator hand-over (acc_in / acc_out of thfhe_mk_rotate_partial_dev) through mk_blind_rotate_pair2k_kernel: ring of degree 2048,
+    # l = 3, five gates (a lone last gate), two ranks with one party each on the one GPU
+    outs = run_two_ranks(tmp_path, "hip", dict(n=24, parties=2), gates=5, chunks=1, timeout=900, pset="MK4-N2048", extra_env=dict(THFHE_TEST_PAIR0="1"))
     for o in outs:
         assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt", "replica")), o
