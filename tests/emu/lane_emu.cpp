@@ -547,3 +547,146 @@ void emu_mk_extract_2k(const int64_t *acc, int32_t *out) {
     for (int ln = 0; ln < 64; ln++) extract_64_n<2048>(ln, acc, acc + 2048, out);
 }
 }
+
+// ---- table-free twisted transforms ("tq" form: N = 2048 two-gate kernels) and the ring of degree 4096 (four twisted quarters) -----------
+namespace {
+struct WaveTQ {
+    cplx T1a[512], T1b[512], T2[64], scratch[512], ratio[64], roots4k[256];
+    cplx xbuf[512];
+    W64 w[64];
+    WaveTQ() {
+        make_twiddles_2048(T1a, T1b);
+        make_twiddles_1024(scratch, T2);
+        make_lane_ratio_2048(ratio);
+        make_lane_roots_4096(roots4k);
+        for (int l = 0; l < 64; l++) w[l] = W64{T2[1 * 8 + (l & 7)]};
+    }
+    template <int T, int DEN>
+    LaneRoots roots(int l) const {
+        if (DEN == 32) return LaneRoots{T == 1 ? T1a[l] : T1b[l], ratio[l]};
+        return LaneRoots{roots4k[((T - 1) / 4) * 64 + l], ratio[l]};
+    }
+    template <int T, int DEN>
+    void fwd(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) fwdtq_seg1<T, DEN>(z[l], roots<T, DEN>(l));
+        lanes_transpose_hi3(z);
+        for (int l = 0; l < 64; l++) fwds_seg2_st(l, z[l], xbuf, w[l]);
+        for (int l = 0; l < 64; l++) fwds_seg3(l, z[l], xbuf);
+    }
+    template <int T, int DEN>
+    void inv(cplx (*z)[8]) {
+        for (int l = 0; l < 64; l++) invs_seg1(l, z[l], xbuf, w[l]);
+        for (int l = 0; l < 64; l++) {
+            invs_seg2_ld(l, z[l], xbuf);
+            dft8<-1>(z[l]);
+        }
+        lanes_transpose_hi3(z);
+        for (int l = 0; l < 64; l++) invtq_seg3<T, DEN>(z[l], roots<T, DEN>(l));
+    }
+};
+}  // namespace
+
+extern "C" {
+// N = 2048: the table-free form gives the spectra of the table form (same order); returns the largest difference
+double emu_tq_vs_table_2k(const double *zin) {
+    Wave2K wt;
+    WaveTQ wq;
+    static cplx z[64][16], y0[64][8], y1[64][8], q0[64][8], q1[64][8];
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 16; m++) z[l][m] = cplx{zin[2 * (l + 64 * m)], zin[2 * (l + 64 * m) + 1]};
+    for (int l = 0; l < 64; l++) split2048(z[l], y0[l], y1[l]);
+    memcpy(q0, y0, sizeof(y0));
+    memcpy(q1, y1, sizeof(y1));
+    wt.fwd<1>(y0);
+    wt.fwd<5>(y1);
+    wq.fwd<1, 32>(q0);
+    wq.fwd<5, 32>(q1);
+    double worst = 0;
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) {
+            worst = __builtin_fmax(worst, __builtin_fabs(y0[l][m].re - q0[l][m].re) + __builtin_fabs(y0[l][m].im - q0[l][m].im));
+            worst = __builtin_fmax(worst, __builtin_fabs(y1[l][m].re - q1[l][m].re) + __builtin_fabs(y1[l][m].im - q1[l][m].im));
+        }
+    // and the inverse pair returns 1024 z
+    wq.inv<1, 32>(q0);
+    wq.inv<5, 32>(q1);
+    static cplx lo[64][8], hi[64][8];
+    for (int l = 0; l < 64; l++) merge2048(q0[l], q1[l], lo[l], hi[l]);
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) {
+            worst = __builtin_fmax(worst, __builtin_fabs(lo[l][m].re / 1024 - z[l][m].re) + __builtin_fabs(lo[l][m].im / 1024 - z[l][m].im));
+            worst = __builtin_fmax(worst, __builtin_fabs(hi[l][m].re / 1024 - z[l][m + 8].re) + __builtin_fabs(hi[l][m].im / 1024 - z[l][m + 8].im));
+        }
+    return worst;
+}
+// N = 4096: exact negacyclic product of a small-digit polynomial d (|d| <= 2^8) with a Torus64 polynomial k, through the radix-4 split, the
+// four twisted quarter transforms, limb spectra scaled by 1/2048, inverse, merge and rounding -- the arithmetic of r4k_rotate_kernel.
+// Returns the worst distance of an inverse output from an integer.
+double emu_polymul_4k(const int32_t *d, const int64_t *k, int64_t *out) {
+    WaveTQ w;
+    static cplx yd[4][64][8], yk[4][4][64][8], S[4][4][64][8];
+    auto fwd4 = [&](cplx (*y)[64][8]) {
+        w.fwd<1, 64>(y[0]);
+        w.fwd<5, 64>(y[1]);
+        w.fwd<9, 64>(y[2]);
+        w.fwd<13, 64>(y[3]);
+    };
+    for (int l = 0; l < 64; l++)
+        for (int m = 0; m < 8; m++) {
+            cplx u[4];
+            for (int s = 0; s < 4; s++) u[s] = cplx{(double)d[l + 64 * m + 512 * s], (double)d[l + 64 * m + 512 * s + 2048]};
+            pre4096(u);
+            yd[0][l][m] = comb4096<0>(u);
+            yd[1][l][m] = comb4096<1>(u);
+            yd[2][l][m] = comb4096<2>(u);
+            yd[3][l][m] = comb4096<3>(u);
+        }
+    fwd4(yd);
+    for (int h = 0; h < 4; h++) {
+        for (int l = 0; l < 64; l++)
+            for (int m = 0; m < 8; m++) {
+                cplx u[4];
+                for (int s = 0; s < 4; s++) {
+                    double a[4], b[4];
+                    split_limbs64(k[l + 64 * m + 512 * s], a);
+                    split_limbs64(k[l + 64 * m + 512 * s + 2048], b);
+                    u[s] = cplx{a[h], b[h]};
+                }
+                pre4096(u);
+                yk[h][0][l][m] = comb4096<0>(u);
+                yk[h][1][l][m] = comb4096<1>(u);
+                yk[h][2][l][m] = comb4096<2>(u);
+                yk[h][3][l][m] = comb4096<3>(u);
+            }
+        fwd4(yk[h]);
+    }
+    double worst = 0;
+    for (int q = 0; q < 4096; q++) out[q] = 0;
+    for (int h = 0; h < 4; h++) {
+        for (int t = 0; t < 4; t++)
+            for (int l = 0; l < 64; l++)
+                for (int m = 0; m < 8; m++) {
+                    const cplx a = yd[t][l][m], b = cplx{yk[h][t][l][m].re * (1.0 / 2048), yk[h][t][l][m].im * (1.0 / 2048)};
+                    S[h][t][l][m] = cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+                }
+        w.inv<1, 64>(S[h][0]);
+        w.inv<5, 64>(S[h][1]);
+        w.inv<9, 64>(S[h][2]);
+        w.inv<13, 64>(S[h][3]);
+        for (int l = 0; l < 64; l++)
+            for (int m = 0; m < 8; m++) {
+                cplx z[4];
+                merge4096(S[h][0][l][m], S[h][1][l][m], S[h][2][l][m], S[h][3][l][m], z);
+                for (int s = 0; s < 4; s++) {
+                    const int c = l + 64 * m + 512 * s;
+                    worst = __builtin_fmax(worst, __builtin_fabs(z[s].re - __builtin_rint(z[s].re)));
+                    worst = __builtin_fmax(worst, __builtin_fabs(z[s].im - __builtin_rint(z[s].im)));
+                    out[c] = (int64_t)((uint64_t)out[c] + ((uint64_t)round_i64(z[s].re) << (16 * h)));
+                    out[c + 2048] = (int64_t)((uint64_t)out[c + 2048] + ((uint64_t)round_i64(z[s].im) << (16 * h)));
+                }
+            }
+    }
+    return worst;
+}
+}
+

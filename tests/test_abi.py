@@ -108,8 +108,11 @@ def test_new_entry_points_validate_arguments_without_a_device():
     # N = 2048 is a multi-key ring degree only, and only up to l = 3
     rc = L.thfhe_mk_ctx_create(C.byref(thfhe.make_params("MK4-N2048", l=4, Bgbit=4)), p64, p32, 0, C.byref(h))
     assert rc == -2 and b"l <= 3" in L.thfhe_last_error()
-    rc = L.thfhe_mk_ctx_create(C.byref(thfhe.make_params("MK4", N=4096)), p64, p32, 0, C.byref(h))
+    rc = L.thfhe_mk_ctx_create(C.byref(thfhe.make_params("MK4", N=8192)), p64, p32, 0, C.byref(h))
     assert rc == -2
+    # N = 4096 holds six row parts: l x ceil(Bgbit / 9) <= 3
+    rc = L.thfhe_mk_ctx_create(C.byref(thfhe.make_params("MK64-fft", l=2)), p64, p32, 0, C.byref(h))
+    assert rc == -2 and b"N = 4096 needs" in L.thfhe_last_error()
     if L.thfhe_device_count() == 0:
         rc = L.thfhe_mk_ctx_create(C.byref(thfhe.make_params("MK4-N2048")), p64, p32, 0, C.byref(h))
         assert rc == -3 and b"no usable HIP device" in L.thfhe_last_error()

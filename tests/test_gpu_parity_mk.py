@@ -184,6 +184,29 @@ def test_mk256_two_level_wide_base_gadget_bit_exact(O, n, parties):
     ck.close()
 
 
+@pytest.mark.parametrize("name,n,parties", [("MK64-fft", 6, 2), ("MK512", 4, 3), ("MK64-fft", 2, 64)])   # the last one: all 64 parties
+def test_mk_ring_4096_sets_bit_exact(O, name, n, parties):
+    # mktfhe_parameters_64party_3gen_for_fft / _512party_3gen (J/mk_api.jl:277-283, 316-322): ring of degree 4096, one level with a 27-bit base
+    # = three 9-bit digit parts, six row parts; r4k_rotate_kernel (radix-4 split into four twisted 512-point transforms, two passes per step).
+    # Gadget, ring and key-switch shape of the reference sets; LWE dimension and party count reduced.  Zero mask words included.
+    import thfhe
+    p = O.make_params(name, n=n, parties=parties)
+    s = O.SIGMAS[name]
+    K = O.MKKeys(p, 91, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    ck = thfhe.MKCloudKey(thfhe.make_params(**p.as_dict()), K.bk, K.ksk, device=0)
+    assert ck.rotation_kernel_name(4) == "r4k_rotate_kernel"
+    a = np.array([0, 0, 1, 1, 1]); b = np.array([0, 1, 0, 1, 1]); c = np.array([1, 0, 1, 0, 0])
+    ca, cb, cc = (K.encrypt_bits(v, s["lwe"], 70 + q) for q, v in enumerate((a, b, c)))
+    assert np.array_equal(K.decrypt_bits(ck.gates(thfhe.NAND, ca, cb)), ~(a.astype(bool) & b.astype(bool)))
+    ca[1, 2] = cb[1, 2] = 0
+    for op, args in ((O.NAND, (ca, cb)), (O.XOR, (ca, cb)), (O.AND3, (ca, cb, cc)), (O.MUX, (ca, cb, cc))):
+        assert np.array_equal(ck.gates(op, *args), orc.gates(op, *args)), op
+    ref = np.stack([orc.keyswitch(orc.bootstrap_wo_keyswitch(r)) for r in ca[:2]])
+    assert np.array_equal(thfhe.mk_bootstrap_3gen(ck, thfhe.MU8_64, ca[:2]), ref)
+    ck.close()
+
+
 def test_mk16_full_size_bit_exact(O):
     # mktfhe_parameters_16party_3gen AS WRITTEN (J/mk_api.jl:214-220): P = 16, n = 590, N = 2048, l = 1, Bgbit = 26, ks 4/3 -- 9 440 sequential
     # CMuxes per gate through the three-part digit split and the shifted key-row copies of mk_expand_parts_kernel at the REAL party count

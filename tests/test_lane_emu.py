@@ -221,3 +221,32 @@ def test_mk_cmux_2048_bit_exact(E, O):
     f = O.lib().oracle_t64tot32
     exp = [f(int(acc[0, 0]))] + [f(int(((-int(acc[0, 2048 - q])) + 2**63) % 2**64 - 2**63)) for q in range(1, 2048)] + [f(int(acc[1, 0]))]
     assert np.array_equal(out, np.array(exp, np.int32)) and ref.shape == (2049,)
+
+
+def test_table_free_twisted_transforms_equal_the_table_form(E):
+    # "tq" form (two-gate N = 2048 kernels, no T1 tables): same spectra in the same order as the table form, and its inverse pair returns 1024 z
+    rng = np.random.default_rng(4)
+    z = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)
+    zin = np.ascontiguousarray(np.stack([z.real, z.imag], -1)).ravel()
+    E.emu_tq_vs_table_2k.restype = C.c_double
+    assert E.emu_tq_vs_table_2k(dptr(zin)) < 1e-10
+
+
+def test_ring_4096_product_exact_with_margin(E, O):
+    # the arithmetic of r4k_rotate_kernel (radix-4 split, four twisted 512-point quarter transforms, four 16-bit limbs, 1/2048 in the key
+    # spectra): digits of the 9-bit parts (|d| <= 256) times a Torus64 polynomial == the exact negacyclic convolution mod 2^64, and every
+    # inverse output within 1e-3 of an integer on an adversarial input (all digits +-256, key words +-2^63 pattern) as well as a random one
+    E.emu_polymul_4k.restype = C.c_double
+    rng = np.random.default_rng(6)
+    N = 4096
+    cases = [(rng.integers(-256, 257, N).astype(np.int32), rng.integers(-2**63, 2**63, N, dtype=np.int64)),
+             (np.where(rng.integers(0, 2, N) == 1, 256, -256).astype(np.int32), np.where(rng.integers(0, 2, N) == 1, 2**63 - 1, -2**63).astype(np.int64))]
+    for d, k in cases:
+        out = np.zeros(N, np.int64)
+        margin = E.emu_polymul_4k(O.p32(d), O.p64(k), O.p64(out))
+        # exact reference: negacyclic convolution with Python integers reduced mod 2^64 (numpy object arithmetic is too slow at N = 4096:
+        # use the oracle's exact 64-bit product)
+        ref = np.zeros(N, np.int64)
+        O.lib().oracle_polymul_schoolbook64(O.p64(d.astype(np.int64)), O.p64(k), N, O.p64(ref))
+        assert np.array_equal(out, ref)
+        assert margin < 1e-3, margin

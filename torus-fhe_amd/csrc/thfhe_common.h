@@ -230,16 +230,16 @@ __device__ __forceinline__ void wave_fft_inv_t(int lane, cplx (&z)[8], cplx *xb,
     invt_seg3<T>(lane, z, xb, T1t);
 }
 // "qs" form of the twisted halves: first transpose in registers, pass-1 twiddles from per-lane roots (no T1 table), one LDS crossing
-template <int T>
+template <int T, int DEN = 32>
 __device__ __forceinline__ void wave_fft_fwd_tq(int lane, cplx (&z)[8], cplx *xb, const LaneRoots &r, const W64 &w) {
-    fwdtq_seg1<T>(z, r);
+    fwdtq_seg1<T, DEN>(z, r);
     wave_transpose_hi3(z);
     wave_sync();
     fwds_seg2_st(lane, z, xb, w);
     wave_sync();
     fwds_seg3(lane, z, xb);
 }
-template <int T>
+template <int T, int DEN = 32>
 __device__ __forceinline__ void wave_fft_inv_tq(int lane, cplx (&z)[8], cplx *xb, const LaneRoots &r, const W64 &w) {
     wave_sync();
     invs_seg1(lane, z, xb, w);
@@ -247,7 +247,7 @@ __device__ __forceinline__ void wave_fft_inv_tq(int lane, cplx (&z)[8], cplx *xb
     invs_seg2_ld(lane, z, xb);
     dft8<-1>(z);
     wave_transpose_hi3(z);
-    invtq_seg3<T>(z, r);
+    invtq_seg3<T, DEN>(z, r);
 }
 
 #endif

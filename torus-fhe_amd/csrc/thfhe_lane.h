@@ -723,10 +723,28 @@ THFHE_FN void invt_seg3(int lane, cplx (&z)[8], const cplx *xbuf, const cplx *T1
 // "qs" form of the twisted halves (the two-gate N = 2048 kernel, whose LDS has no room for the two T1 tables): the pass-1 twiddles are
 // rebuilt from per-lane roots, T1_T[k0][lane] = b_T s^k0 with b_T = zeta^(T lane), s = zeta^(8 lane), and the first transpose happens in
 // registers (wave_transpose_hi3) -- same spectra order, so key spectra made by the table variant multiply with these.
-template <int T>
+THFHE_FN cplx e64(int q) {  // exp(i pi q / 64)
+    constexpr double C[33] = {1.0, 0.998795456205172392715, 0.995184726672196886245, 0.989176509964780973452, 0.980785280403230449126,
+                              0.970031253194543992604, 0.956940335732208864936, 0.941544065183020778413, 0.923879532511286756128,
+                              0.903989293123443331586, 0.881921264348355029713, 0.857728610000272069902, 0.831469612302545237079,
+                              0.803207531480644909807, 0.773010453362736960811, 0.740951125354959091176, 0.707106781186547524401,
+                              0.671558954847018400625, 0.634393284163645498215, 0.595699304492433343467, 0.555570233019602224743,
+                              0.514102744193221726594, 0.471396736825997648556, 0.427555093430282094321, 0.382683432365089771728,
+                              0.336889853392220050689, 0.290284677254462367636, 0.242980179903263889948, 0.195090322016128267848,
+                              0.146730474455361751659, 0.0980171403295606019942, 0.049067674327418014255, 0.0};
+    const int quad = (q >> 5) & 3, r = q & 31;
+    const double c = C[r], s = C[32 - r];
+    return quad == 0 ? cplx{c, s} : quad == 1 ? cplx{-s, c} : quad == 2 ? cplx{-c, -s} : cplx{s, -c};
+}
+// pass-1 constants zeta^(64 T m) of the twisted halves (DEN = 32: ring of degree 2048) / quarters (DEN = 64: degree 4096)
+template <int DEN>
+THFHE_FN cplx e_den(int q) {
+    return DEN == 32 ? e32(q) : e64(q);
+}
+template <int T, int DEN = 32>
 THFHE_FN void fwdtq_seg1(cplx (&z)[8], const LaneRoots &r) {
 #pragma unroll
-    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], e32(T * m));
+    for (int m = 1; m < 8; m++) z[m] = cmul(z[m], e_den<DEN>(T * m));
     dft8<+1>(z);
     const cplx s2 = cmul(r.s, r.s);
     cplx e = r.b, o = cmul(r.b, r.s);
@@ -740,7 +758,7 @@ THFHE_FN void fwdtq_seg1(cplx (&z)[8], const LaneRoots &r) {
         }
     }
 }
-template <int T>
+template <int T, int DEN = 32>
 THFHE_FN void invtq_seg3(cplx (&z)[8], const LaneRoots &r) {
     const cplx s2 = cmul(r.s, r.s);
     cplx e = r.b, o = cmul(r.b, r.s);
@@ -755,7 +773,7 @@ THFHE_FN void invtq_seg3(cplx (&z)[8], const LaneRoots &r) {
     }
     dft8<-1>(z);
 #pragma unroll
-    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], e32(T * m));
+    for (int m = 1; m < 8; m++) z[m] = cmul_conj(z[m], e_den<DEN>(T * m));
 }
 // radix-2 split of the 16 folded points a lane holds (z[m] <-> j = lane + 64 m) and its inverse (unnormalised: x2)
 THFHE_FN void split2048(const cplx (&z)[16], cplx (&y0)[8], cplx (&y1)[8]) {
@@ -775,6 +793,38 @@ THFHE_FN void merge2048(const cplx (&a)[8], const cplx (&b)[8], cplx (&lo)[8], c
         lo[m] = cadd(a[m], b[m]);
         hi[m] = cplx{(d.re + d.im) * R, (d.im - d.re) * R};  // e^{-i pi/4} d
     }
+}
+// ---- N = 4096 (the 64-party "for fft" and 512-party 3-gen sets, J/mk_api.jl:277-283, 316-322): 2048 complex points = one radix-4 split +
+// four twisted 512-point transforms.  z_j = p_j + i p_{j+2048}, P_k = sum_{j<2048} z_j zeta^(j(4k+1)), zeta = exp(i pi / 4096).  With
+// j = j' + 512 s and k = 4 k'' + t:   zeta^(j(4k+1)) = omega_512^(j' k'') zeta^(j'(4t+1)) (e^{i pi/8} i^t)^s, so
+//     P_{4k''+t} = sum_{j'<512} y^t_j' zeta^(T j') omega_512^(j' k''),   y^t_j' = sum_s (e^{i pi/8} i^t)^s z_{j'+512 s},   T = 4t + 1
+// i.e. quarter t is the twisted 512-point transform with twist T in {1, 5, 9, 13}: constants exp(i pi T m / 64), per-lane root
+// b_T = zeta^(T lane), the same ratio exp(i pi lane / 256) as on the ring of degree 2048.  Spectrum order [quarter][slot m][lane].
+// u_s = e^{i pi s/8} z_s for the four points of a radix-4 group
+THFHE_FN void pre4096(cplx (&z)[4]) {
+    constexpr double C8 = 0.923879532511286756128, S8 = 0.382683432365089771728, R = 0.70710678118654752440;
+    z[1] = cplx{z[1].re * C8 - z[1].im * S8, z[1].re * S8 + z[1].im * C8};
+    z[2] = cplx{(z[2].re - z[2].im) * R, (z[2].re + z[2].im) * R};
+    z[3] = cplx{z[3].re * S8 - z[3].im * C8, z[3].re * C8 + z[3].im * S8};
+}
+// y^t = u0 + i^t u1 + (-1)^t u2 + (-i)^t u3
+template <int QT>
+THFHE_FN cplx comb4096(const cplx (&u)[4]) {
+    if (QT == 0) return cplx{u[0].re + u[1].re + u[2].re + u[3].re, u[0].im + u[1].im + u[2].im + u[3].im};
+    if (QT == 1) return cplx{u[0].re - u[1].im - u[2].re + u[3].im, u[0].im + u[1].re - u[2].im - u[3].re};
+    if (QT == 2) return cplx{u[0].re - u[1].re + u[2].re - u[3].re, u[0].im - u[1].im + u[2].im - u[3].im};
+    return cplx{u[0].re + u[1].im - u[2].re - u[3].im, u[0].im - u[1].re - u[2].im + u[3].re};
+}
+// inverse (unnormalised: x4): z_s = e^{-i pi s/8} (a0 + (-i)^s a1 + (-1)^s a2 + i^s a3)
+THFHE_FN void merge4096(const cplx &a0, const cplx &a1, const cplx &a2, const cplx &a3, cplx (&z)[4]) {
+    constexpr double C8 = 0.923879532511286756128, S8 = 0.382683432365089771728, R = 0.70710678118654752440;
+    z[0] = cplx{a0.re + a1.re + a2.re + a3.re, a0.im + a1.im + a2.im + a3.im};
+    const cplx v1{a0.re + a1.im - a2.re - a3.im, a0.im - a1.re - a2.im + a3.re};
+    const cplx v2{a0.re - a1.re + a2.re - a3.re, a0.im - a1.im + a2.im - a3.im};
+    const cplx v3{a0.re - a1.im - a2.re + a3.im, a0.im + a1.re - a2.im - a3.re};
+    z[1] = cplx{v1.re * C8 + v1.im * S8, v1.im * C8 - v1.re * S8};
+    z[2] = cplx{(v2.re + v2.im) * R, (v2.im - v2.re) * R};
+    z[3] = cplx{v3.re * S8 + v3.im * C8, v3.im * S8 - v3.re * C8};
 }
 // generic-degree integer helpers (NN = ring degree, a power of two)
 template <int NN>
@@ -862,6 +912,15 @@ inline void make_lane_ratio_2048(cplx *s /*64*/) {
         long double a = PI * (long double)(8 * lane) / 2048.0L;
         s[lane] = cplx{(double)cosl(a), (double)sinl(a)};
     }
+}
+// N = 4096: b_T[lane] = exp(i pi T lane / 4096) for the four twists T = 1, 5, 9, 13 (roots[q * 64 + lane], q = quarter)
+inline void make_lane_roots_4096(cplx *roots /*256*/) {
+    const long double PI = 3.14159265358979323846264338327950288L;
+    for (int q = 0; q < 4; q++)
+        for (int lane = 0; lane < 64; lane++) {
+            long double a = PI * (long double)((4 * q + 1) * lane) / 4096.0L;
+            roots[q * 64 + lane] = cplx{(double)cosl(a), (double)sinl(a)};
+        }
 }
 // N = 2048: T1_T[k0*64 + lane] = exp(i pi lane (8 k0 + T) / 2048) for the two twists T = 1 (even outputs) and T = 5 (odd outputs)
 inline void make_twiddles_2048(cplx *T1a /*512, T = 1*/, cplx *T1b /*512, T = 5*/) {

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -529,6 +530,8 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
 
 // the batched N = 2048 rotation (any number of row parts, two-part digits) shared with the KMS scheme
 #include "thfhe_rot2k.h"
+// the ring of degree 4096 (the 64-party "for fft" and the 512-party 3-gen sets)
+#include "thfhe_rot4k.h"
 
 // ------------------------------------------------------------------------------------------------------
 // N = 2048 throughput kernel: one 512-thread workgroup = TWO gates (batches above one gate per CU).  The one-gate kernel above spends half
@@ -778,13 +781,13 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
 
 
 // initial accumulator of the batched path, in global memory: acc = (0, X^{-barb} * (mu, ..., mu))   (J/3gen_mk_internals.jl:91-92)
-__global__ __launch_bounds__(256) void mk_acc_init_2k_kernel(const int32_t *__restrict__ barb, int64_t mu, long jobs, int64_t *__restrict__ acc) {
+__global__ __launch_bounds__(256) void mk_acc_init_2k_kernel(const int32_t *__restrict__ barb, int64_t mu, long jobs, int64_t *__restrict__ acc, int N = 2048) {
     const long job = blockIdx.x;
     if (job >= jobs) return;
     const int b = barb[job];
-    for (int q = threadIdx.x; q < 2048; q += 256) {
-        acc[job * 4096 + q] = 0;
-        acc[job * 4096 + 2048 + q] = (((q + b) & 4095) & 2048) ? (int64_t)(0ull - (uint64_t)mu) : mu;
+    for (int q = threadIdx.x; q < N; q += 256) {
+        acc[job * 2 * N + q] = 0;
+        acc[job * 2 * N + N + q] = (((q + b) & (2 * N - 1)) & N) ? (int64_t)(0ull - (uint64_t)mu) : mu;
     }
 }
 
@@ -901,6 +904,27 @@ int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1,
 
 int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a) {
     const dim3 grid((unsigned)a.jobs), block(512);
+    if (c->p.N == 4096) {
+        // ring of degree 4096: accumulators in global memory, rotated in place by r4k_rotate_kernel (thfhe_rot4k.h)
+        int64_t *acc = a.acc_out;
+        if (!acc) {
+            if ((size_t)a.jobs * 2 > c->cap_acc) {   // cap_acc counts 4096-word accumulators
+                (void)hipFree(c->d_acc);
+                c->d_acc = nullptr;
+                c->cap_acc = 0;
+                THFHE_HIP(hipMalloc(&c->d_acc, (size_t)a.jobs * 8192 * sizeof(int64_t)));
+                c->cap_acc = (size_t)a.jobs * 2;
+            }
+            acc = c->d_acc;
+        }
+        if (!a.acc_in) hipLaunchKernelGGL(mk_acc_init_2k_kernel, dim3((unsigned)a.jobs), dim3(256), 0, c->stream, a.barb, a.mu, a.jobs, acc, 4096);
+        else if (a.acc_in != acc) THFHE_HIP(hipMemcpyAsync(acc, a.acc_in, (size_t)a.jobs * 8192 * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+        R4KArgs k{c->d_bk, c->d_tw, a.bara, acc, a.jobs, a.pn, c->p.l, c->p.Bgbit, c->parts, c->pw, a.w_pad};
+        hipLaunchKernelGGL(r4k_rotate_kernel, grid, block, 0, c->stream, k);
+        if (!a.acc_out) hipLaunchKernelGGL(mk_extract_kernel, grid, dim3(256), 0, c->stream, (const int64_t *)acc, a.out, a.jobs, 4096);
+        THFHE_HIP(hipGetLastError());
+        return THFHE_OK;
+    }
     if (c->batched) {
         // accumulators in global memory: start (unless the caller hands one in), rotate by all P n key bits in place, then extract (unless the caller wants
         // the accumulator itself)
@@ -1040,7 +1064,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     if (!p || !bk_coeff || !ksk || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
     *out = nullptr;
     if (p->torus_bits != 64) return thfhe_fail(THFHE_E_UNSUPPORTED, "thfhe_mk_ctx_create is the Torus64 3-gen multi-key path");
-    if ((p->N != 1024 && p->N != 2048) || p->k != 1) return thfhe_fail(THFHE_E_UNSUPPORTED, "only N = 1024 / 2048, k = 1 is implemented");
+    if ((p->N != 1024 && p->N != 2048 && p->N != 4096) || p->k != 1) return thfhe_fail(THFHE_E_UNSUPPORTED, "only N = 1024 / 2048 / 4096, k = 1 is implemented");
     if (p->N == 2048 && p->l > 3) return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 2048 needs decomposition length l <= 3");
     if (p->parties < 1 || p->parties > 512) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= parties <= 512");
     // digits beyond 10 bit are cut into balanced parts of <= 9 bit (N = 2048 only: the sets that use a wide base live on that ring,
@@ -1050,7 +1074,10 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     // l x parts <= 3: the one-pass N = 2048 kernel; more row parts (the 256-party set: l = 2, Bgbit = 18 -> 2 x 2 parts) go through the batched
     // rotation of thfhe_rot2k.h, which knows one- and two-part digits.  Exactness: 2 l parts N 2^(part bits - 1) 2^15 <= 2^37 (section 4.3).
     const bool batched = p->N == 2048 && (p->l * parts > 3 || (parts <= 2 && getenv("THFHE_MK_FORCE_BATCHED") != nullptr));   // the switch: developer A/B of the two N = 2048 paths
-    if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || (!batched && p->l * p->Bgbit > 32) || p->l * p->Bgbit > 64 || (parts > 1 && p->N != 2048) || (batched && parts > 2) ||
+    const bool ring4k = p->N == 4096;   // thfhe_rot4k.h: at most six row parts, digits from the top 32 bits; |sum| <= 6 x 4096 x 2^8 x 2^15 = 2^37.6 (one level more than N = 2048)
+    if (ring4k && (p->l < 1 || 2 * p->l * parts > 6 || p->l * p->Bgbit > 32 || (double)(2 * p->l * parts) * 4096.0 * (double)(1 << ((parts > 1 ? pw : p->Bgbit) - 1)) * 32768.0 > 274877906944.0))
+        return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 4096 needs l x ceil(Bgbit / 9) <= 3, l*Bgbit <= 32 and the FP64 exactness bound 2 l parts N 2^(part bits - 1) 2^15 <= 2^38");
+    if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || (!batched && p->l * p->Bgbit > 32) || p->l * p->Bgbit > 64 || (parts > 1 && p->N == 1024) || (batched && parts > 2) ||
         (batched && (double)(2 * p->l * parts) * 2048.0 * (double)(1 << ((parts > 1 ? pw : p->Bgbit) - 1)) * 32768.0 > 137438953472.0))
         return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 4, l*Bgbit <= 32 (64 on the batched path), and Bgbit <= 10 (FP64 exactness bound) unless N = 2048 with l x ceil(Bgbit / 9) <= 3 or two-part digits");
     if (p->n < 1 || p->n > 767) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= n <= 767");
@@ -1087,9 +1114,11 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto &e : c->ev) CK(hipEventCreate(&e));
-    std::vector<cplx> tw(1088 + 128 + 64);  // N = 1024: T1[512] T2[64]; N = 2048: T1(twist 1)[512] T1(twist 5)[512] T2[64]; [1088..): per-lane roots (N = 1024); [1216..): pass-1 ratio (N = 2048)
+    std::vector<cplx> tw(1088 + 128 + 64 + 256);   // [1280..): per-lane roots of the four quarter twists (N = 4096)
+    make_lane_roots_4096(tw.data() + 1280);
+    // N = 1024: T1[512] T2[64]; N = 2048: T1(twist 1)[512] T1(twist 5)[512] T2[64]; [1088..): per-lane roots (N = 1024); [1216..): pass-1 ratio (N = 2048)
     make_lane_ratio_2048(tw.data() + 1216);
-    if (p->N == 2048) {
+    if (p->N >= 2048) {   // (N = 4096 reads only T2, the ratio and its own roots: the table-free transforms)
         std::vector<cplx> unused(512);
         make_twiddles_2048(tw.data(), tw.data() + 512);
         make_twiddles_1024(unused.data(), tw.data() + 1024);
@@ -1099,7 +1128,35 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     make_lane_roots_1024(tw.data() + 1088);
     CK(hipMalloc(&c->d_tw, tw.size() * sizeof(cplx)));
     CK(hipMemcpyAsync(c->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream));
-    if (batched) {
+    if (ring4k) {
+        // key table of thfhe_rot4k.h: [party * n + i][row part rp = (j l + level) parts + part][output o][limb][quarter][512]; row part (j, level, part)
+        // of output o is part_{mk_part_index(j, o)}[level] shifted left by part * pw bits (wrapping).  Staged party by party.
+        const int RP = 2 * p->l * parts, N = 4096;
+        const size_t polys_per_party = (size_t)p->n * RP * 2;
+        CK(hipMalloc(&c->d_bk, (size_t)p->parties * polys_per_party * 4 * 2048 * sizeof(cplx)));
+        CK(hipMalloc(&d_coeff, polys_per_party * N * sizeof(int64_t)));
+        std::vector<int64_t> host(polys_per_party * N);
+        for (int q = 0; q < p->parties; q++) {
+            for (int i = 0; i < p->n; i++)
+                for (int j = 0; j < 2; j++)
+                    for (int lv = 0; lv < p->l; lv++)
+                        for (int part = 0; part < parts; part++)
+                            for (int o = 0; o < 2; o++) {
+                                const int64_t *src = bk_coeff + ((((size_t)q * p->n + i) * 4 + mk_part_index(j, o)) * p->l + lv) * N;
+                                const int rp = (j * p->l + lv) * parts + part;
+                                int64_t *dst = host.data() + (((size_t)i * RP + rp) * 2 + o) * N;
+                                const int sh = part * pw;
+                                for (int t = 0; t < N; t++) dst[t] = (int64_t)((uint64_t)src[t] << sh);
+                            }
+            CK(hipMemcpyAsync(d_coeff, host.data(), host.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(r4k_key_transform_kernel, dim3((unsigned)((polys_per_party * 4 + 3) / 4)), dim3(256), 0, c->stream, d_coeff, (long)polys_per_party,
+                               c->d_tw, c->d_bk + (size_t)q * polys_per_party * 4 * 2048);
+            CK(hipGetLastError());
+            CK(hipStreamSynchronize(c->stream));   // `host` is reused for the next party
+        }
+        (void)hipFree(d_coeff);
+        d_coeff = nullptr;
+    } else if (batched) {
         // key table of thfhe_rot2k.h: [party * n + i][row part rp = (j l + level) parts + part][output o][limb][half][512]; row part (j, level,
         // part) of output o is part_{mk_part_index(j, o)}[level] shifted left by part * pw bits (wrapping): d (*) K = d_lo (*) K + d_hi (*) (K << pw).
         // Staged party by party (the 256-party set: 194 MB of coefficients per party, 185 GB of spectra in all).

@@ -78,7 +78,7 @@ struct MKKSArgs {
 // grid = (gates, parties, nsplit): block (g, p, s) key-switches coordinates [s*N/nsplit, (s+1)*N/nsplit) of gate g with
 // party p's key and adds its partial sum into the zero-initialised output with integer atomics (order-independent: bit-exact)
 __global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a, int nsplit) {
-    __shared__ uint32_t sA[2048];
+    __shared__ uint32_t sA[4096];   // extracted mask words of this block (N <= 4096)
     __shared__ uint32_t sRed[4][768];
     const long g = blockIdx.x;
     const int p = blockIdx.y;

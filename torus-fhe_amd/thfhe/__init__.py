@@ -54,6 +54,9 @@ PARAM_SETS = {
     "MK32-fft": dict(n=680, N=2048, k=1, l=1, Bgbit=25, ks_t=5, ks_basebit=3, torus_bits=64, parties=32),   # mktfhe_parameters_32party_3gen_for_fft, mk_api.jl:255-261
     # 256 parties: TWO levels with an 18-bit base (mk_api.jl:304-310) -> two 9-bit parts per level, eight row parts: the batched N = 2048 rotation
     "MK256": dict(n=740, N=2048, k=1, l=2, Bgbit=18, ks_t=8, ks_basebit=2, torus_bits=64, parties=256),
+    # the ring of degree 4096: mktfhe_parameters_64party_3gen_for_fft, mktfhe_parameters_512party_3gen (mk_api.jl:277-283, 316-322); 27-bit base -> three 9-bit parts
+    "MK64-fft": dict(n=720, N=4096, k=1, l=1, Bgbit=27, ks_t=5, ks_basebit=3, torus_bits=64, parties=64),
+    "MK512": dict(n=730, N=4096, k=1, l=1, Bgbit=27, ks_t=5, ks_basebit=3, torus_bits=64, parties=512),
     # CCS scheme (mk_bootstrap / mk_gate_nand): mktfhe_parameters_2party / _4party, mk_api.jl:4-10,56-62
     "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
     "CCS4": dict(n=560, N=1024, k=1, l=4, Bgbit=8, ks_t=8, ks_basebit=2, torus_bits=32, parties=4),
@@ -80,6 +83,8 @@ SIGMAS = {
     "MK128": dict(lwe=2.0**-17.42, bk=2.0**-62.0, ks=2.0**-17.42),
     "MK32-fft": dict(lwe=2.0**-17.68, bk=2.0**-62.0, ks=2.0**-17.68),
     "MK256": dict(lwe=2.0**-19.24, bk=2.0**-62.0, ks=2.0**-19.24),
+    "MK64-fft": dict(lwe=2.0**-18.72, bk=2.0**-62.0, ks=2.0**-18.72),
+    "MK512": dict(lwe=2.0**-18.98, bk=2.0**-62.0, ks=2.0**-18.98),
     "CCS2": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS4": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS8": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
@@ -535,6 +540,8 @@ class MKCloudKey:
     def rotation_kernel_name(self, rotations):
         """The blind-rotation kernel a batch of `rotations` is dispatched to (mk_launch_rotation in thfhe_mk.hip)."""
         p = self.params
+        if p.N == 4096:
+            return "r4k_rotate_kernel"
         if p.N == 2048:
             le = p.l * (((p.Bgbit + 8) // 9) if p.Bgbit > 10 else 1)
             pair = rotations > getattr(self, "_pair_threshold", 256)
