@@ -14,7 +14,6 @@
 //   mk_keyswitch_kernel       P key switches of the extracted sample + the cross-party combine of b
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 #include <type_traits>
 #include <mutex>
 #include <new>
@@ -1073,7 +1072,7 @@ int thfhe_mk_ctx_create(const thfhe_params *p, const int64_t *bk_coeff, const in
     const int pw = parts > 1 ? (p->Bgbit + parts - 1) / parts : 0;
     // l x parts <= 3: the one-pass N = 2048 kernel; more row parts (the 256-party set: l = 2, Bgbit = 18 -> 2 x 2 parts) go through the batched
     // rotation of thfhe_rot2k.h, which knows one- and two-part digits.  Exactness: 2 l parts N 2^(part bits - 1) 2^15 <= 2^37 (section 4.3).
-    const bool batched = p->N == 2048 && (p->l * parts > 3 || (parts <= 2 && getenv("THFHE_MK_FORCE_BATCHED") != nullptr));   // the switch: developer A/B of the two N = 2048 paths
+    const bool batched = p->N == 2048 && p->l * parts > 3;
     const bool ring4k = p->N == 4096;   // thfhe_rot4k.h: at most six row parts, digits from the top 32 bits; |sum| <= 6 x 4096 x 2^8 x 2^15 = 2^37.6 (one level more than N = 2048)
     if (ring4k && (p->l < 1 || 2 * p->l * parts > 6 || p->l * p->Bgbit > 32 || (double)(2 * p->l * parts) * 4096.0 * (double)(1 << ((parts > 1 ? pw : p->Bgbit) - 1)) * 32768.0 > 274877906944.0))
         return thfhe_fail(THFHE_E_UNSUPPORTED, "N = 4096 needs l x ceil(Bgbit / 9) <= 3, l*Bgbit <= 32 and the FP64 exactness bound 2 l parts N 2^(part bits - 1) 2^15 <= 2^38");
