@@ -28,17 +28,18 @@ if os.path.exists(tj):
     lines.append("bench line of the traced run: `" + open(tj).read().strip().splitlines()[-1] + "`\n")
 ks = newest(f"{tag}_trace/**/*kernel_stats.csv")
 if ks:
-    lines.append("## kernel trace (`rocprofv3 --kernel-trace --stats`; warm-up, one-party probe, the 256-gate batch and the fast_boot batch together)\n")
+    lines.append("## kernel trace (`rocprofv3 --kernel-trace --stats`; warm-up, one-party probe, the gate batch and the fast_boot batch together)\n")
     lines.append("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|")
     for row in csv.DictReader(open(ks)):
         lines.append(f"| `{row['Name'][:80]}` | {row['Calls']} | {float(row['AverageNs'])/1e6:.4f} | {float(row['TotalDurationNs'])/1e6:.2f} | {float(row['Percentage']):.2f} |")
     lines.append("")
-# per-dispatch durations of the two kernels of interest: the full-batch launches are the longest ones
+KEYS = ("kms_tlev_rotate_pair_kernel", "kms_tlev_rotate_kernel", "pm_mac_kernel")   # two jobs per workgroup (launches above 256 jobs) / one job / products
+# per-dispatch durations of the kernels of interest: the full-batch launches are the longest ones
 dur = defaultdict(list)
 kt = newest(f"{tag}_trace/**/*kernel_trace.csv")
 if kt:
     for row in csv.DictReader(open(kt)):
-        for key in ("kms_tlev_rotate_kernel", "pm_mac_kernel"):
+        for key in KEYS:
             if key in row["Kernel_Name"]:
                 dur[key].append((float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-9)
 ctr = defaultdict(lambda: defaultdict(list))
@@ -47,7 +48,7 @@ for sub in ("fetch", "sq", "lds", "f64"):
     if not f:
         continue
     for row in csv.DictReader(open(f)):
-        for key in ("kms_tlev_rotate_kernel", "pm_mac_kernel"):
+        for key in KEYS:
             if key in row["Kernel_Name"]:
                 ctr[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
                 if "Scratch_Size" in row and row["Scratch_Size"] != "":
@@ -62,7 +63,7 @@ def top(vals, k):
 
 
 out = {}
-for key, k in (("kms_tlev_rotate_kernel", 2), ("pm_mac_kernel", 4)):
+for key, k in (("kms_tlev_rotate_pair_kernel", 2), ("kms_tlev_rotate_kernel", 2), ("pm_mac_kernel", 4)):
     if not dur[key] or not ctr[key]:
         continue
     t = top(dur[key], k)
@@ -76,7 +77,7 @@ for key, k in (("kms_tlev_rotate_kernel", 2), ("pm_mac_kernel", 4)):
              vector_insts=c.get("SQ_INSTS_VALU"), fp64_insts=f64, lds_insts=c.get("SQ_INSTS_LDS"), bank_conflicts=c.get("SQ_LDS_BANK_CONFLICT"),
              scratch_bytes_per_lane=c.get("_scratch"), vgprs=c.get("_vgpr"), launches_averaged=k)
     out[key] = d
-    lines.append(f"## `{key}`: the {k} largest launches (the 256-gate batch{' , one per party' if 'tlev' in key else ''})\n")
+    lines.append(f"## `{key}`: the {k} largest launches{' (one per party)' if 'tlev' in key else ''}\n")
     for n, v in d.items():
         if v is not None:
             lines.append(f"* {n} = {v:.6g}")

@@ -78,7 +78,7 @@ struct MKKSArgs {
 // grid = (gates, parties, nsplit): block (g, p, s) key-switches coordinates [s*N/nsplit, (s+1)*N/nsplit) of gate g with
 // party p's key and adds its partial sum into the zero-initialised output with integer atomics (order-independent: bit-exact)
 __global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a, int nsplit) {
-    __shared__ uint32_t sA[4096];   // extracted mask words of this block (N <= 4096)
+    __shared__ uint32_t sA[2048];   // this block's slice of the extracted mask: N / nsplit <= 2048 words (N = 4096 is launched with nsplit >= 2)
     __shared__ uint32_t sRed[4][768];
     const long g = blockIdx.x;
     const int p = blockIdx.y;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a, int nspli
     const uint32_t prec_offset = 1u << (32 - (1 + a.basebit * a.t));
     const int32_t *u = a.u + (size_t)g * a.u_rec + (size_t)p * a.u_pstride;
     const int i_lo = (int)blockIdx.z * (a.N / nsplit), i_hi = i_lo + a.N / nsplit;
-    for (int q = i_lo + tid; q < i_hi; q += 256) sA[q] = (uint32_t)u[q] + prec_offset;
+    for (int q = i_lo + tid; q < i_hi; q += 256) sA[q - i_lo] = (uint32_t)u[q] + prec_offset;
     __syncthreads();
     const int base1 = (1 << a.basebit) - 1;
     const uint32_t mask = (uint32_t)base1;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a, int nspli
     for (int q = 0; q < 12; q++) r[q] = 0;
     const int32_t *kp = a.ksk + (size_t)p * a.N * a.t * base1 * a.row_words;
     for (int i = i_lo + wave; i < i_hi; i += 4) {
-        const uint32_t ai = sA[i];
+        const uint32_t ai = sA[i - i_lo];
         for (int j = 0; j < a.t; j++) {
             const uint32_t d = (ai >> (32 - (j + 1) * a.basebit)) & mask;
             if (d == 0) continue;
