@@ -323,7 +323,9 @@ def run_party(args, p, rank, world, barrier, max_reduce, backend, device):
     ab = algorithmic_bytes(p)
     per_rot = jobs_per_launch * (ab["bk"] * (last - first) // p.parties + 2 * 2 * p.N * 8)   # this rank's share of the key stream + accumulator in / out
     avg_ms = float(np.mean(rot_ms)) if rot_ms else None
-    roof = {"kernel": ("mk_blind_rotate_coop2k_kernel" if p.N == 2048 else "mk_blind_rotate_coop_kernel") + f"<{p.l}>",
+    # the piece launches take the accumulator in / out: the one-gate kernels on the ring of degree 1024 (the two-gate kernel there has no hand-over),
+    # the one- or two-gate kernel by launch size on the ring of degree 2048
+    roof = {"kernel": (be.ck.rotation_kernel_name(int(jobs_per_launch)) if p.N >= 2048 else f"mk_blind_rotate_coop_kernel<{p.l}>"),
             "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step, "gates_per_launch": jobs_per_launch,
             "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
             "counters_source": "no PMC pass for the party-sharded piece launches (the kernel is the replicated mode's; see that mode's line)",
