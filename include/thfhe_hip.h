@@ -120,6 +120,9 @@ int thfhe_last_timings(thfhe_ctx *ctx, float ms[4]);
 
 /* ---- 3-gen multi-key (Torus64 ring) --------------------------------------------------------------- */
 typedef struct thfhe_mk_ctx thfhe_mk_ctx;
+/* Ring degrees: N = 1024 (l <= 4, Bgbit <= 10), N = 2048 (l <= 3; bases of 11 .. 27 bit are cut into balanced 9-bit digit parts: the 16 .. 256-party
+ * sets of J/mk_api.jl:214-310), N = 4096 (at most six digit rows: the 64-party "for fft" and the 512-party set, J/mk_api.jl:277-283, 316-322).
+ * bk_coeff int64[P][n][4][l][N] (part_1 .. part_4 of MKBootstrapKeyPart_3gen), ksk int32[P][N][t][base-1][n+1]. */
 int thfhe_mk_ctx_create(const thfhe_params *params, const int64_t *bk_coeff, const int32_t *ksk, int device,
                         thfhe_mk_ctx **out);
 void thfhe_mk_ctx_destroy(thfhe_mk_ctx *ctx);
