@@ -59,6 +59,7 @@ PARAM_SETS = {
     "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
     "CCS4": dict(n=560, N=1024, k=1, l=4, Bgbit=8, ks_t=8, ks_basebit=2, torus_bits=32, parties=4),
     "CCS8": dict(n=560, N=1024, k=1, l=5, Bgbit=6, ks_t=8, ks_basebit=2, torus_bits=32, parties=8),   # mktfhe_parameters_8party, mk_api.jl:111-117
+    "CCS16": dict(n=560, N=1024, k=1, l=12, Bgbit=2, ks_t=8, ks_basebit=2, torus_bits=32, parties=16),   # mktfhe_parameters_16party, mk_api.jl:185-191
 }
 # noise standard deviations (torus units): J/api.jl:101-115 (SK-128: 2^-15 / 2^-25 per src/libthfhe.cpp:325-326),
 # J/mk_api.jl:32-38 (MK2), :84-90 (MK4)
@@ -83,6 +84,7 @@ SIGMAS = {
     "CCS2": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS4": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS8": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
+    "CCS16": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
 }
 
 

@@ -21,7 +21,10 @@ def make(O, name, **over):
                                        ("CCS2", dict(n=9, l=2, Bgbit=8, parties=3)),          # l = 2: 4 groups per batch, two output tasks per wave
                                        ("CCS4", dict(n=6)),                                    # l = 4, 4 parties: one group per batch... (G = 2)
                                        ("CCS2", dict(n=7, l=5, Bgbit=6, parties=1)),          # one group per batch, single party
-                                       ("CCS8", dict(n=3))])                                   # the reference's 8-party set: 45 digit rows per stage
+                                       ("CCS8", dict(n=3)),                                    # the reference's 8-party set: 45 digit rows per stage
+                                       ("CCS16", dict(n=2)),                                   # the reference's 16-party set (ccs_blind_rotate_wide_kernel): l = 12, 204 digit rows per stage
+                                       ("CCS16", dict(n=3, parties=3)),                        # twelve levels on four polynomials: two level batches per polynomial
+                                       ("CCS8", dict(n=2, l=3, parties=11))])                  # more than eight parties with a short gadget (one level batch)
 def test_ccs_reduced_bit_exact(O, name, over):
     import thfhe
     p, s, K, orc, ck = make(O, name, **over)

@@ -203,6 +203,141 @@ __global__ __launch_bounds__(512, 2) void ccs_blind_rotate_kernel(CCSArgs a) {
     if (threadIdx.x == 0) out[(size_t)P * 1024] = sAcc[P][0];
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// The 16-party set (mktfhe_parameters_16party, J/mk_api.jl:185-191: l = 12, Bgbit = 2, 17 accumulator polynomials, 204 digit rows per stage):
+// same arithmetic, other shape.  The accumulator (68 KiB) stays in LDS; the v polynomials of a step live in global memory (`vbuf`, 68 KiB per
+// job: written with integer atomics in stage 1, read back once in stage 2 -- both through the L2, agent-scope accesses); the digit rows of ONE
+// polynomial go through the eight slots in level batches of up to eight, the four (u|v, limb) output tasks of the group accumulating partial
+// spectral sums over the level batches; stage 2 walks all (P+1) l rows in batches of eight with the eight (w0|w1, limb, parity) roles of the
+// kernel above.  Correctness first: at 8 960 CMuxes of ~420 transforms per gate this set is seconds per gate on any hardware.
+// LDS: T1 8 + acc 68 + slots 64 = 140 KiB.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kCcsWideMaxParties = 16;
+
+__global__ __launch_bounds__(512, 2) void ccs_blind_rotate_wide_kernel(CCSArgs a, int32_t *__restrict__ vbuf) {
+    __shared__ cplx sT1[512];
+    __shared__ int32_t sAcc[kCcsWideMaxParties + 1][1024];
+    __shared__ cplx sSlot[8][512];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    sT1[threadIdx.x] = a.tw[threadIdx.x];
+    const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
+    const long job = blockIdx.x;
+    const int P = a.parties, L = a.l, Bgbit = a.Bgbit;
+    const int32_t *bara = a.bara + job * a.w_pad;
+    const uint32_t offset = decomp_offset32(L, Bgbit);
+    int32_t *V = vbuf + (size_t)job * (P + 1) * 1024;
+    for (int q = threadIdx.x; q < (P + 1) * 1024; q += 512) {
+        int32_t v = 0;
+        if (q >= P * 1024) {
+            const int e = ((q - P * 1024) + a.barb[job]) & 2047;  // X^{-barb} * (mu, ..., mu)
+            v = (e & 1024) ? (int32_t)(0u - (uint32_t)a.mu) : a.mu;
+        }
+        (&sAcc[0][0])[q] = v;
+    }
+    __syncthreads();
+
+    for (int pj = 0; pj < P * a.n; pj++) {  // party-major, key index inner: J/mk_internals.jl:816-828
+        const int ai = bara[pj];
+        if (ai == 0) continue;
+        const int a2n = ai & 2047, party = pj / a.n;
+        const cplx *ue = a.bk + (size_t)pj * 3 * L * 1024;  // d | f0 | f1, each [l][limb][512]
+        for (int q = threadIdx.x; q < (P + 1) * 1024; q += 512) __hip_atomic_store(V + q, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __syncthreads();
+        // ---- stage 1: u and v of every polynomial ---------------------------------------------------------------------------
+        for (int grp = 0; grp <= P; grp++) {
+            const int kind = (wave >> 1) & 1, h = wave & 1;   // output task of waves 0..3: (u|v, limb)
+            const cplx *key = kind == 0 ? ue : (grp < P ? a.pk + (size_t)grp * L * 1024 : a.crs);
+            cplx S[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) S[m] = cplx{0.0, 0.0};
+            for (int lb = 0; lb < L; lb += 8) {
+                const int nb = L - lb < 8 ? L - lb : 8;
+                if (wave < nb) {
+                    uint32_t t[16];
+                    cplx z[8];
+                    load_rotated16(lane, sAcc[grp], a2n, offset, t);
+                    digits_to_z(t, lb + wave + 1, Bgbit, z);
+                    wave_fft_fwd_s(lane, z, sSlot[wave], sT1, w64);
+                    wave_sync();
+#pragma unroll
+                    for (int m = 0; m < 8; m++) sSlot[wave][m * 64 + lane] = z[m];
+                }
+                __syncthreads();  // spectra of the level batch published
+                if (wave < 4)
+                    for (int lv = 0; lv < nb; lv++) ccs_mac(lane, S, sSlot[lv], key + ((size_t)(lb + lv) * 2 + h) * 512);
+                __syncthreads();  // spectra consumed: the slots are free for the next level batch / transpose scratch
+            }
+            if (wave < 4) {   // every rotated read of acc[grp] is done (barrier above): its u may be added now
+                wave_fft_inv_s(lane, S, sSlot[wave], sT1, w64);
+                const bool neg = kind == 1 && grp == P;  // v_0 = -<g^{-1}(t_b), crs.a>
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const int q = lane + 64 * m;
+                    uint32_t vr = round_lo32(S[m].re) << (16 * h), vi = round_lo32(S[m].im) << (16 * h);
+                    if (neg) vr = 0u - vr, vi = 0u - vi;
+                    if (kind == 0) {
+                        atomicAdd(reinterpret_cast<unsigned int *>(sAcc[grp]) + q, vr);
+                        atomicAdd(reinterpret_cast<unsigned int *>(sAcc[grp]) + q + 512, vi);
+                    } else {
+                        __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(V + (size_t)grp * 1024) + q, vr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(reinterpret_cast<unsigned int *>(V + (size_t)grp * 1024) + q + 512, vi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            __syncthreads();  // u of the group complete; scratch free
+        }
+        __threadfence();
+        __syncthreads();  // every v is in the L2
+        // ---- stage 2: acc.b += sum <g^{-1}(v_i), f0>, acc.a[party] += sum <g^{-1}(v_i), f1> -------------------------------------
+        {
+            const int o = wave >> 2, h = (wave >> 1) & 1, par = wave & 1;  // role: (w0|w1, limb, row parity)
+            const cplx *key = ue + (size_t)(1 + o) * L * 1024;
+            cplx S[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) S[m] = cplx{0.0, 0.0};
+            const int rows = (P + 1) * L;
+            for (int r0 = 0; r0 < rows; r0 += 8) {
+                const int nb = rows - r0 < 8 ? rows - r0 : 8;
+                if (wave < nb) {
+                    const int r = r0 + wave;
+                    uint32_t t[16];
+                    cplx z[8];
+                    const int32_t *v = V + (size_t)(r / L) * 1024;
+#pragma unroll
+                    for (int m = 0; m < 16; m++) t[m] = (uint32_t)__hip_atomic_load(v + lane + 64 * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + offset;
+                    digits_to_z(t, (r % L) + 1, Bgbit, z);
+                    wave_fft_fwd_s(lane, z, sSlot[wave], sT1, w64);
+                    wave_sync();
+#pragma unroll
+                    for (int m = 0; m < 8; m++) sSlot[wave][m * 64 + lane] = z[m];
+                }
+                __syncthreads();
+                for (int slot = par; slot < nb; slot += 2) ccs_mac(lane, S, sSlot[slot], key + ((size_t)((r0 + slot) % L) * 2 + h) * 512);
+                __syncthreads();  // spectra consumed before the next batch (or the inverse transforms) reuse the slots
+            }
+            wave_fft_inv_s(lane, S, sSlot[wave], sT1, w64);
+            unsigned int *dst = reinterpret_cast<unsigned int *>(o == 0 ? sAcc[P] : sAcc[party]);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int q = lane + 64 * m;
+                atomicAdd(dst + q, round_lo32(S[m].re) << (16 * h));
+                atomicAdd(dst + q + 512, round_lo32(S[m].im) << (16 * h));
+            }
+        }
+        __syncthreads();  // accumulator updated before the next rotation reads it
+    }
+    // mk_rlwe_extract_sample (J/mk_internals.jl:141-148): a[:, p] = reverse_polynomial(acc.a_p), b = acc.b[0]
+    int32_t *out = a.out + job * ((size_t)P * 1024 + 1);
+    for (int q = threadIdx.x; q < P * 1024; q += 512) {
+        const int p = q >> 10, j = q & 1023;
+        out[q] = j == 0 ? sAcc[p][0] : (int32_t)(0u - (uint32_t)sAcc[p][1024 - j]);
+    }
+    if (threadIdx.x == 0) out[(size_t)P * 1024] = sAcc[P][0];
+}
+
 }  // namespace
 
 struct thfhe_ccs_ctx {
@@ -214,13 +349,15 @@ struct thfhe_ccs_ctx {
     int row_words = 0, w_pad = 0, words = 0;
     size_t cap = 0;
     int32_t *d_bara = nullptr, *d_barb = nullptr, *d_u = nullptr, *d_in[2] = {nullptr, nullptr}, *d_out = nullptr;
+    int32_t *d_v = nullptr;   // wide shape (more than 8 parties or 8 levels): the v polynomials of a step, int32[jobs][P+1][1024]
+    bool wide = false;
     std::mutex mu;
 };
 
 namespace {
 int ccs_ensure(thfhe_ccs_ctx *c, size_t jobs) {
     if (jobs <= c->cap) return THFHE_OK;
-    for (int32_t **q : {&c->d_bara, &c->d_barb, &c->d_u, &c->d_in[0], &c->d_in[1], &c->d_out}) {
+    for (int32_t **q : {&c->d_bara, &c->d_barb, &c->d_u, &c->d_in[0], &c->d_in[1], &c->d_out, &c->d_v}) {
         (void)hipFree(*q);
         *q = nullptr;
     }
@@ -232,6 +369,7 @@ int ccs_ensure(thfhe_ccs_ctx *c, size_t jobs) {
     THFHE_HIP(hipMalloc(&c->d_in[0], jobs * rec * sizeof(int32_t)));
     THFHE_HIP(hipMalloc(&c->d_in[1], jobs * rec * sizeof(int32_t)));
     THFHE_HIP(hipMalloc(&c->d_out, jobs * rec * sizeof(int32_t)));
+    if (c->wide) THFHE_HIP(hipMalloc(&c->d_v, jobs * ((size_t)c->p.parties + 1) * 1024 * sizeof(int32_t)));
     c->cap = jobs;
     return THFHE_OK;
 }
@@ -248,7 +386,8 @@ int ccs_run(thfhe_ccs_ctx *c, MKLin L, const int32_t *in0, const int32_t *in1, i
     hipLaunchKernelGGL(mk_prologue_kernel, pg, dim3(256), 0, c->stream, c->d_in[0], in1 ? c->d_in[1] : c->d_in[0], c->d_in[0], L, L, (const int32_t *)nullptr, 1,
                        c->words, c->w_pad, 11, (long)count, c->d_bara, c->d_barb);
     CCSArgs a{c->d_bk, c->d_pk, c->d_crs, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)count, c->p.parties, c->p.n, c->p.l, c->w_pad, c->p.Bgbit, mu};
-    hipLaunchKernelGGL(ccs_blind_rotate_kernel, dim3((unsigned)count), dim3(512), 0, c->stream, a);
+    if (c->wide) hipLaunchKernelGGL(ccs_blind_rotate_wide_kernel, dim3((unsigned)count), dim3(512), 0, c->stream, a, c->d_v);
+    else hipLaunchKernelGGL(ccs_blind_rotate_kernel, dim3((unsigned)count), dim3(512), 0, c->stream, a);
     MKKSArgs k{c->d_ksk, c->d_u, c->d_out, (long)count, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words, 1024, c->p.parties * 1024 + 1, 1024};
     const int nsplit = count * c->p.parties <= 64 ? 16 : (count * c->p.parties <= 256 ? 4 : 1);
     THFHE_HIP(hipMemsetAsync(c->d_out, 0, bytes, c->stream));
@@ -268,9 +407,9 @@ int thfhe_ccs_ctx_create(const thfhe_params *p, const int32_t *bk, const int32_t
     *out = nullptr;
     if (p->torus_bits != 32) return thfhe_fail(THFHE_E_UNSUPPORTED, "thfhe_ccs_ctx_create is the Torus32 CCS multi-key path");
     if (p->N != 1024 || p->k != 1) return thfhe_fail(THFHE_E_UNSUPPORTED, "only N = 1024, k = 1 is implemented");
-    if (p->parties < 1 || p->parties > kCcsMaxParties) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= parties <= 8");
-    if (p->l < 1 || p->l > 8 || p->Bgbit < 1 || p->Bgbit > 10 || p->l * p->Bgbit > 32)
-        return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 8, Bgbit <= 10, l*Bgbit <= 32");
+    if (p->parties < 1 || p->parties > kCcsWideMaxParties) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= parties <= 16");
+    if (p->l < 1 || p->l > 16 || p->Bgbit < 1 || p->Bgbit > 10 || p->l * p->Bgbit > 32)
+        return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= l <= 16, Bgbit <= 10, l*Bgbit <= 32");
     if ((long)(p->parties + 1) * p->l * (1L << (p->Bgbit - 1)) > 3072)
         return thfhe_fail(THFHE_E_UNSUPPORTED, "(parties+1) * l * 2^(Bgbit-1) exceeds the FP64 exactness bound of the stage-2 sums");
     if (p->n < 1 || p->n > 767) return thfhe_fail(THFHE_E_UNSUPPORTED, "need 1 <= n <= 767");
@@ -283,6 +422,7 @@ int thfhe_ccs_ctx_create(const thfhe_params *p, const int32_t *bk, const int32_t
     if (!c) return thfhe_fail(THFHE_E_NOMEM, "out of host memory");
     c->p = *p;
     c->device = device;
+    c->wide = p->parties > kCcsMaxParties || p->l > 8;   // the 16-party shape: ccs_blind_rotate_wide_kernel
     c->words = p->parties * p->n;
     c->w_pad = (c->words + 3) & ~3;
     c->row_words = 128 * ((p->n + 1 + 127) / 128);
@@ -333,7 +473,7 @@ void thfhe_ccs_ctx_destroy(thfhe_ccs_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *q : {(void *)c->d_bk, (void *)c->d_pk, (void *)c->d_crs, (void *)c->d_tw, (void *)c->d_ksk, (void *)c->d_bara, (void *)c->d_barb, (void *)c->d_u,
-                    (void *)c->d_in[0], (void *)c->d_in[1], (void *)c->d_out})
+                    (void *)c->d_in[0], (void *)c->d_in[1], (void *)c->d_out, (void *)c->d_v})
         (void)hipFree(q);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

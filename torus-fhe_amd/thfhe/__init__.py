@@ -61,6 +61,7 @@ PARAM_SETS = {
     "CCS2": dict(n=560, N=1024, k=1, l=3, Bgbit=9, ks_t=8, ks_basebit=2, torus_bits=32, parties=2),
     "CCS4": dict(n=560, N=1024, k=1, l=4, Bgbit=8, ks_t=8, ks_basebit=2, torus_bits=32, parties=4),
     "CCS8": dict(n=560, N=1024, k=1, l=5, Bgbit=6, ks_t=8, ks_basebit=2, torus_bits=32, parties=8),   # mktfhe_parameters_8party, mk_api.jl:111-117
+    "CCS16": dict(n=560, N=1024, k=1, l=12, Bgbit=2, ks_t=8, ks_basebit=2, torus_bits=32, parties=16),   # mktfhe_parameters_16party, mk_api.jl:185-191
 }
 
 
@@ -88,6 +89,7 @@ SIGMAS = {
     "CCS2": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS4": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
     "CCS8": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
+    "CCS16": dict(lwe=3.05e-5, bk=3.72e-9, ks=3.05e-5),
 }
 
 
