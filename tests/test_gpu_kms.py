@@ -22,7 +22,8 @@ def setup(O, name, n, parties=None, seed=7):
     return p, K, orc, ck
 
 
-@pytest.mark.parametrize("name,n,parties", [("KMS2", 12, None), ("KMS2-fast", 5, None), ("KMS4", 6, None), ("KMS8", 4, 3), ("KMS16", 3, 3), ("KMS32", 3, 2)])
+@pytest.mark.parametrize("name,n,parties", [("KMS2", 12, None), ("KMS2-fast", 5, None), ("KMS4", 6, None), ("KMS8", 4, 3), ("KMS16", 3, 3), ("KMS32", 3, 2),
+                                            ("KMS4-fast", 4, 3), ("KMS8-fast", 3, 2), ("KMS16-fast", 3, 2)])   # the `_fast` twins: uni gadgets 7/6, 7/4, 7/4
 def test_kms_pieces_and_gates_bit_exact(O, name, n, parties):
     # KMS2: l_gsw = 3, Bgbit 13 -> two-part digits, 12 row parts (two LDS batches); KMS4: l_gsw = 5, Bgbit 8 -> 10 row parts;
     # KMS8 gadgets (l_gsw = 4, Bgbit 11 -> 16 row parts, three batches; l_lev = 3; l_uni = 8) on three parties; KMS16 / KMS32 gadgets

@@ -110,6 +110,11 @@ KMS_PARAM_SETS = {
     "KMS8": dict(n=560, N=2048, parties=8, l_gsw=4, bg_gsw=11, l_lev=3, bg_lev=6, l_uni=8, bg_uni=4, ks_t=8, ks_basebit=2),
     "KMS16": dict(n=560, N=2048, parties=16, l_gsw=5, bg_gsw=9, l_lev=3, bg_lev=6, l_uni=9, bg_uni=4, ks_t=8, ks_basebit=2),    # mk_api.jl:194-202
     "KMS32": dict(n=560, N=2048, parties=32, l_gsw=6, bg_gsw=8, l_lev=3, bg_lev=7, l_uni=16, bg_uni=2, ks_t=8, ks_basebit=2),   # mk_api.jl:225-233
+    # the `_fast` twins (mk_api.jl:74-82, 130-138, 204-212, 235-243): other uni-encryption gadgets, same rotation; the 32-party one equals `_new`
+    "KMS4-fast": dict(n=560, N=2048, parties=4, l_gsw=5, bg_gsw=8, l_lev=2, bg_lev=8, l_uni=7, bg_uni=6, ks_t=8, ks_basebit=2),
+    "KMS8-fast": dict(n=560, N=2048, parties=8, l_gsw=4, bg_gsw=11, l_lev=3, bg_lev=6, l_uni=7, bg_uni=4, ks_t=8, ks_basebit=2),
+    "KMS16-fast": dict(n=560, N=2048, parties=16, l_gsw=5, bg_gsw=9, l_lev=3, bg_lev=6, l_uni=7, bg_uni=4, ks_t=8, ks_basebit=2),
+    "KMS32-fast": dict(n=560, N=2048, parties=32, l_gsw=6, bg_gsw=8, l_lev=3, bg_lev=7, l_uni=16, bg_uni=2, ks_t=8, ks_basebit=2),
 }
 
 
