@@ -291,7 +291,10 @@ def run_party(args, p, rank, world, barrier, max_reduce, backend, device):
     B = args.batch * topo["group_size"]
     # a pipeline of W ranks and C slices runs at C / (C + W - 1) of its steady rate, and a slice should still fill the chip (>= 256 gates:
     # one workgroup per CU); with one rank per group there is no pipeline and the batch goes down in one launch
-    chunks = args.pipeline_chunks if args.pipeline_chunks > 0 else (1 if topo["group_size"] == 1 else max(1, B // 256))
+    # slices of a group's batch in flight along the party pipeline: 256 gates each (one workgroup per CU) on the ring of degree 1024, 512 on the ring of
+    # degree 2048, where launches above 256 gates run two gates per workgroup (8.5 k against 6.3 k gates/s per GPU)
+    slice_gates = 512 if p.N >= 2048 else 256
+    chunks = args.pipeline_chunks if args.pipeline_chunks > 0 else (1 if topo["group_size"] == 1 else max(1, B // slice_gates))
     ev = PartyShardedEvaluator(p, be, group=group, pipeline_chunks=chunks)
     gseed = 0x5EED0002 + 2 * topo["group"]      # every rank of a group sees the same ciphertexts (mk_internals.jl:23-37)
     rng = np.random.default_rng(gseed)
@@ -362,7 +365,7 @@ def main():
     ap.add_argument("--mode", choices=("replicated", "party"), default="replicated",
                     help="replicated: every GPU holds all keys and runs its own batch; party: the parties' keys are dealt over the GPUs (3-gen sets)")
     ap.add_argument("--pipeline-chunks", type=int, default=0,
-                    help="--mode party: slices of a group's batch in flight along the party pipeline (0 = auto: one per 256 gates, 1 when a group is one rank)")
+                    help="--mode party: slices of a group's batch in flight along the party pipeline (0 = auto: one per 256 gates -- 512 on the ring of degree 2048 --, 1 when a group is one rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-per-thread", type=int, default=None, help="gates per host thread in the exact-oracle sample of the CPU baseline (default 8; 1 for multi-key sets; the FFT-engine sample is 8x that)")
     ap.add_argument("--dry-topology", action="store_true", help="rank start-up + rendezvous + barrier only (no GPU): rehearsal of --gpus N")
