@@ -92,6 +92,18 @@ int thfhe_gates_mixed(thfhe_ctx *ctx, const int32_t *ops, const int32_t *in0, co
  * the wire table stays in HBM and the host is not synchronised between levels.
  * stats (optional) int64[4] = {levels, bootstrap launches, blind rotations, widest level}. */
 int thfhe_dag_run(thfhe_ctx *ctx, int32_t *wires, size_t n_inputs, const int32_t *gates, size_t n_gates, int64_t *stats);
+/* `instances` independent evaluations of ONE gate list, level by level: a level's launch holds instances x its gates.  This is the
+ * reference's loop over test records around one circuit (`for i < test_row_size`, src/KNN_medical_data.cpp:676-691): the deep, narrow
+ * part of a decision (a ripple carry holds 1-3 gates per level) fills the chip only when many records walk it side by side.
+ *   inputs     HOST int32[instances][n_inputs][n+1]
+ *   out_wires  HOST wire ids to return (n_out of them); NULL: every gate wire, i.e. n_inputs .. n_inputs + n_gates - 1
+ *   outputs    HOST int32[instances][n_out (or n_gates)][n+1]
+ * Gate outputs are deterministic functions of their operands, so instance q's wires equal thfhe_dag_run on inputs[q] bit for bit. */
+int thfhe_dag_run_batch(thfhe_ctx *ctx, const int32_t *inputs, size_t n_inputs, const int32_t *gates, size_t n_gates, size_t instances,
+                        const int32_t *out_wires, size_t n_out, int32_t *outputs, int64_t *stats);
+/* A level whose instances x gates exceed `max_gates` runs as several launches of at most that many gates (default 28 672 = 14 rounds of the
+ * throughput kernel; bounds the staging memory and the launch grid).  1 .. 32 767. */
+int thfhe_set_dag_slice(thfhe_ctx *ctx, size_t max_gates);
 int thfhe_bootstrap(thfhe_ctx *ctx, int32_t mu, const int32_t *x, int32_t *out, size_t count);
 int thfhe_bootstrap_wo_keyswitch(thfhe_ctx *ctx, int32_t mu, const int32_t *x, int32_t *out_N1, size_t count);
 int thfhe_keyswitch(thfhe_ctx *ctx, const int32_t *in_N1, int32_t *out, size_t count);
@@ -108,9 +120,13 @@ int thfhe_gates_dev(thfhe_ctx *ctx, int op, const int32_t *d_in0, const int32_t 
                     int32_t *d_out, size_t count);
 int thfhe_sync(thfhe_ctx *ctx);
 
-/* Batches of at most `max_jobs` rotations run on the cooperative latency kernel (one workgroup per gate), larger ones on
- * the LDS-ring throughput kernel (eight gates per workgroup).  0 forces the ring kernel.  Default 1024 (measured crossover on MI355X is ~1150). */
+/* Kernel choice for a batch of rotations (gates; a MUX is two).  Whole rounds of 2 048 rotations (eight per CU of an MI355X) run on the
+ * LDS-ring throughput kernel, eight gates per workgroup.  The remainder r runs on the cooperative latency kernel (one workgroup per gate) if
+ * r <= the cooperative threshold (default 768), on the four-wave shape of the ring kernel (four gates per workgroup, one wave per SIMD) if
+ * r <= the ring4 threshold (default 1 024), on both if r <= ring4 + 256, else on one more eight-wave round.  Both thresholds 0: everything
+ * on the eight-wave kernel.  Every shape computes the same words. */
 int thfhe_set_coop_threshold(thfhe_ctx *ctx, int max_jobs);
+int thfhe_set_ring4_threshold(thfhe_ctx *ctx, int max_jobs);
 
 /* Per-kernel device timing: when enabled, every *_dev call brackets each kernel with HIP events on the
  * context's stream.  After thfhe_sync, thfhe_last_timings returns milliseconds of the most recent call:
@@ -136,6 +152,10 @@ int thfhe_mk_set_pair_threshold(thfhe_mk_ctx *ctx, long max_single_jobs);
 /* Gate-DAG evaluation for the 3-gen scheme (same contract as thfhe_dag_run; records of P*n+1 words): the reference's multi-key integer
  * circuits mk_add_3gen ... mk_int_mul_3gen (J/3gen_mk_gates.jl:183-362).  Opcodes: NAND / OR / AND / XOR, AND3, MUX, NOT, COPY. */
 int thfhe_mk_dag_run(thfhe_mk_ctx *ctx, int32_t *wires, size_t n_inputs, const int32_t *gates, size_t n_gates, int64_t *stats);
+/* `instances` evaluations of one 3-gen gate list side by side (same contract as thfhe_dag_run_batch; records of P*n+1 words) */
+int thfhe_mk_dag_run_batch(thfhe_mk_ctx *ctx, const int32_t *inputs, size_t n_inputs, const int32_t *gates, size_t n_gates, size_t instances,
+                           const int32_t *out_wires, size_t n_out, int32_t *outputs, int64_t *stats);
+int thfhe_mk_set_dag_slice(thfhe_mk_ctx *ctx, size_t max_gates); /* default 8 192 */
 int thfhe_mk_bootstrap(thfhe_mk_ctx *ctx, int64_t mu, const int32_t *x, int32_t *out, size_t count);
 /* Party-sharded building blocks (optional mode: a rank holds only the keys of a contiguous block of m
  * parties, i.e. a context created with parties = m from those parties' key parts; m = 1 is one rank per party).  Below

@@ -416,3 +416,137 @@ def test_native_dag_executors_on_random_dags(O):
     vals = Cc.evaluate(mk, cir, KM.encrypt_bits(bits, sg["lwe"], 7))
     assert np.array_equal(KM.decrypt_bits(vals), Cc.simulate_mk(cir, bits))
     mk.close()
+
+
+@pytest.mark.gpu
+def test_batched_dag_instances_equal_single_runs(O):
+    """thfhe_dag_run_batch / thfhe_mk_dag_run_batch: Q instances of one gate list walk the levels side by side.  Every instance must
+    equal its own thfhe_dag_run bit for bit -- with the level cut into slices that straddle instances, with selected output wires and
+    with all wires -- and sampled gates must equal the oracle."""
+    import thfhe
+    from thfhe import keygen, circuits as Cc
+    rng = np.random.default_rng(21)
+    p = thfhe.make_params("SK-128", n=64)
+    K = keygen.SecretKeySet(p, seed=4)
+    ck = thfhe.CloudKey(p, K.bk, K.ksk, device=0)
+    orc = O.Oracle(O.make_params("SK-128", n=64), K.bk, K.ksk)
+    sk_ops = [thfhe.NAND, thfhe.OR, thfhe.AND, thfhe.XOR, thfhe.XNOR, thfhe.NOR, thfhe.ANDNY, thfhe.ANDYN, thfhe.ORNY, thfhe.ORYN,
+              thfhe.MUX, thfhe.NOT, thfhe.COPY]
+    Q = 7
+    cir = random_dag(rng, 6, 160, sk_ops)
+    gates = np.array(cir.gates, np.int32)
+    bits = rng.integers(0, 2, (Q, 6))
+    enc = np.stack([K.encrypt(bits[q], seed=300 + q) for q in range(Q)])
+    single = np.stack([ck.dag_run(enc[q], gates)[0] for q in range(Q)])
+    for slice_gates in (28672, 5, 1):      # whole levels; slices of 5 and of 1 gate: a slice then straddles instances / classes
+        ck.set_dag_slice(slice_gates)
+        st = {}
+        allw = Cc.evaluate_batch(ck, cir, enc, None, st)
+        assert np.array_equal(allw, single), slice_gates
+        assert st["instances"] == Q and st["rotations"] == Q * cir.census()["rotations"]
+        sel = rng.choice(cir.n_wires(), 37, replace=False)
+        assert np.array_equal(Cc.evaluate_batch(ck, cir, enc, sel), single[:, sel]), slice_gates
+    ck.set_dag_slice(28672)
+    for q in range(Q):
+        assert np.array_equal(K.decrypt(single[q]), Cc.simulate(cir, bits[q]))
+    g = rng.choice(np.flatnonzero(~np.isin(gates[:, 0], (thfhe.NOT, thfhe.COPY))), 24, replace=False)   # sampled gates vs the oracle, all instances
+    for gi in g:
+        op, a, b, c = (int(v) for v in gates[gi])
+        ref = orc.gates(op, single[:, a], single[:, b], single[:, c] if op == thfhe.MUX else None)
+        assert np.array_equal(single[:, cir.n_inputs + gi], ref), gi
+    # argument checks of the C entry point
+    with pytest.raises(thfhe.ThfheError):
+        ck.dag_run_batch(enc, gates, np.array([cir.n_wires()], np.int32))          # output wire out of range
+    out, _ = ck.dag_run_batch(enc[:0], gates)                                       # zero instances: nothing to do
+    assert out.shape == (0, len(cir.gates), p.n + 1)
+    ck.close()
+    # 3-gen engine: all its gate classes, 5 instances, slices of 3 gates
+    pm = O.make_params("MK2", n=64)
+    sg = O.SIGMAS["MK2"]
+    KM = O.MKKeys(pm, 5, sg["bk"], sg["ks"])
+    mk = thfhe.MKCloudKey(thfhe.make_params(**pm.as_dict()), KM.bk, KM.ksk, device=0)
+    mk_ops = [thfhe.NAND, thfhe.OR, thfhe.AND, thfhe.XOR, thfhe.AND3, thfhe.MUX, thfhe.NOT, thfhe.COPY]
+    cir = random_dag(rng, 6, 60, mk_ops)
+    bits = rng.integers(0, 2, (5, 6))
+    enc = np.stack([KM.encrypt_bits(bits[q], sg["lwe"], 40 + q) for q in range(5)])
+    single = np.stack([mk.dag_run(enc[q], np.array(cir.gates, np.int32))[0] for q in range(5)])
+    for slice_gates in (8192, 3):
+        mk.set_dag_slice(slice_gates)
+        assert np.array_equal(Cc.evaluate_batch(mk, cir, enc), single), slice_gates
+    for q in range(5):
+        assert np.array_equal(KM.decrypt_bits(single[q]), Cc.simulate_mk(cir, bits[q]))
+    mk.close()
+
+
+@pytest.mark.gpu
+def test_batched_knn_decisions_on_gpu(O):
+    """The reference's loop over test records (src/KNN_medical_data.cpp:676-691) as one batched evaluation at the reference's size:
+    4 test records x (5 train rows x 14 columns x 32 bit) = 5.0e5 blind rotations through thfhe_dag_run_batch.  Every decision, vote
+    count and sorted distance list must equal the plaintext KNN; >= 200 sampled gates of the batch (operands and outputs fetched with
+    out_wires, all four instances) must equal the oracle bit for bit; record 0 must equal the single-decision path bit for bit."""
+    import os
+    import thfhe
+    from thfhe import keygen, circuits as Cc
+    nb, ncol, ntrain, Q = 32, 14, 5, 4
+    rows = []
+    with open(os.path.join(O.GOLDEN, "data1.csv")) as f:
+        next(f)
+        for line in f:
+            rows.append([int(float(w)) & 0xFFFFFFFF for w in line.strip().split(",")][:ncol])
+            if len(rows) == ntrain + Q:
+                break
+    train, tests = rows[:ntrain], rows[ntrain:]
+    threshold = ntrain // 2
+    p = thfhe.make_params("SK-128")
+    K = keygen.SecretKeySet(p, seed=0x5EED0001)
+    ck = thfhe.CloudKey(p, K.bk, K.ksk, device=0)
+    words = p.n + 1
+    enc = lambda vals, seed: K.encrypt(np.array(sum((bits_msb(v, nb) for v in vals), [])), seed=seed).reshape(len(vals), nb, words)
+    e_tests = np.stack([enc(t, 0x5EED0100 + q) for q, t in enumerate(tests)])
+    e_train = np.stack([enc(r, 0x5EED0200 + j) for j, r in enumerate(train)])
+    thr, az, ao, lo = (enc([v], 0x5EED0300 + q)[0] for q, v in enumerate((threshold, 0, 0xFFFFFFFF, 1)))
+    zero = K.encrypt(np.array([0]), seed=0x5EED0400)[0]
+    plan = Cc.KnnPlan(nb, ncol, ntrain)
+    st = {}
+    res = Cc.knn_decisions_batched(ck, plan, e_tests, e_train, thr, az, ao, lo, zero, stats=st)
+    votes = sum(r[ncol - 1] for r in train)
+    for q, t in enumerate(tests):
+        d = [sum(abs(t[c] - r[c]) for c in range(1, ncol - 1)) & 0xFFFFFFFF for r in train]
+        assert [from_bits(K.decrypt(w)) for w in res["dists"][q]] == d, q
+        assert [from_bits(K.decrypt(w)) for w in res["sorted_dists"][q]] == sorted(d), q
+        assert from_bits(K.decrypt(res["count"][q])) == votes
+        assert bool(K.decrypt(res["decision"][q][None])[0]) == (votes > threshold)
+    assert st["phase1"]["rotations"] + st["phase2"]["rotations"] > 4 * 1.2e5
+    one = Cc.knn_decision_sharded(ck, plan, e_tests[0], e_train, thr, az, ao, lo, zero)
+    for k in ("decision", "count", "sorted_dists", "dists"):
+        assert np.array_equal(one[k], res[k][0]), k
+    # sampled gates of both phases (the wide distance levels, the deep sort / vote chain), all four instances, against the oracle
+    orc = O.Oracle(O.make_params("SK-128"), K.bk, K.ksk)
+    rng = np.random.default_rng(5)
+
+    def sample_against_oracle(cir, inputs, extra_sel, n_two, n_mux):
+        gates = np.array(cir.gates, np.int64)
+        two = np.flatnonzero(gates[:, 0] != thfhe.MUX)
+        mux = np.flatnonzero(gates[:, 0] == thfhe.MUX)
+        pick = np.concatenate([rng.choice(two, n_two, replace=False), rng.choice(mux, n_mux, replace=False)])
+        need = sorted(set(int(w) for g in pick for w in gates[g, 1:] if w >= 0) | set(int(cir.n_inputs + g) for g in pick))
+        pos = {w: i for i, w in enumerate(need)}
+        got_all = Cc.evaluate_batch(ck, cir, inputs, list(extra_sel) + need)
+        got = got_all[:, len(extra_sel):]
+        for op in np.unique(gates[pick, 0]):
+            g = pick[gates[pick, 0] == op]
+            col = lambda k: got[:, [pos[int(w)] for w in gates[g, k]]].reshape(-1, words)
+            ref = orc.gates(int(op), col(1), col(2), col(3) if op == thfhe.MUX else None)
+            assert np.array_equal(got[:, [pos[int(cir.n_inputs + x)] for x in g]].reshape(-1, words), ref), f"opcode {op}"
+        return got_all[:, :len(extra_sel)]
+
+    c1, dist, copies = plan.phase1(ntrain)
+    shared = np.concatenate([e_train.reshape(-1, words), az, ao, lo, zero[None]])
+    in1 = np.stack([np.concatenate([e_tests[q].reshape(-1, words), shared]) for q in range(Q)])
+    sel1 = [w for r in range(ntrain) for col in range(ncol) for w in copies[r][col]] + [w for r in range(ntrain) for w in dist[r]]
+    o1 = sample_against_oracle(c1, in1, sel1, 28, 8)
+    c2, *_ = plan.phase2()
+    tail = np.concatenate([thr, az, ao, lo, zero[None]])
+    in2 = np.concatenate([o1, np.broadcast_to(tail, (Q,) + tail.shape)], axis=1)
+    sample_against_oracle(c2, in2, [], 28, 8)            # (36 + 36) gates x 4 instances = 288 oracle comparisons
+    ck.close()

@@ -27,8 +27,9 @@ def test_single_key_shapes(O, shape):
     a, b, c = (rng.integers(0, 2, G) for _ in range(3))
     ca, cb, cc = (K.encrypt_bits(v, 2.0**-15, 5 + q) for q, v in enumerate((a, b, c)))
     ref_x, ref_m = orc.gates(O.XNOR, ca, cb), orc.gates(O.MUX, ca, cb, cc)
-    for thr in (0, 1 << 20):                      # ring kernel, cooperative kernel
+    for thr, ring4 in ((0, 0), (0, 1024), (1 << 20, 1024)):      # eight-wave ring, four-wave ring, cooperative kernel
         ck.set_coop_threshold(thr)
+        ck.set_ring4_threshold(ring4)
         assert np.array_equal(ck.gates(thfhe.XNOR, ca, cb), ref_x), (shape, thr)
         assert np.array_equal(ck.gates(thfhe.MUX, ca, cb, cc), ref_m), (shape, thr)
     ops = rng.integers(0, 10, G).astype(np.int32)

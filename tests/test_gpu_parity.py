@@ -58,19 +58,20 @@ def test_all_gates_bit_exact_and_truth_tables(O, sk128, gpu128):
 
 
 def test_every_blind_rotate_kernel_bit_exact(O, sk128, gpu128):
-    # the same 12 gates through the cooperative latency kernel (threshold >= jobs) and the LDS-ring kernel (threshold 0)
+    # the same 12 gates through every kernel shape: eight-wave LDS ring (both thresholds 0), four-wave LDS ring, cooperative latency kernel
     import thfhe
     p, K, orc = sk128
     a = np.array([0, 1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 0]); b = np.array([1, 1, 0, 0, 1, 0, 0, 1, 1, 0, 1, 1])
     ca, cb = enc(O, K, a, 45), enc(O, K, b, 46)
     ref = orc.gates(O.XOR, ca, cb)
     try:
-        gpu128.set_coop_threshold(0)
-        assert np.array_equal(gpu128.gates(thfhe.XOR, ca, cb), ref)          # ring kernel, partially filled workgroups
-        gpu128.set_coop_threshold(1 << 20)
-        assert np.array_equal(gpu128.gates(thfhe.XOR, ca, cb), ref)          # cooperative kernel
+        for coop, ring4 in ((0, 0), (0, 1024), (1 << 20, 1024), (5, 6)):     # (5, 6): 6 gates on the four-wave ring + 6 cooperative (12 <= ring4 + 256)
+            gpu128.set_coop_threshold(coop)
+            gpu128.set_ring4_threshold(ring4)
+            assert np.array_equal(gpu128.gates(thfhe.XOR, ca, cb), ref), (coop, ring4)   # partially filled workgroups in both ring shapes
     finally:
-        gpu128.set_coop_threshold(1024)
+        gpu128.set_coop_threshold(768)
+        gpu128.set_ring4_threshold(1024)
 
 
 def test_mux_bit_exact(O, sk128, gpu128):

@@ -47,6 +47,21 @@ SCRIPT = """
     thr, az, ao, lo = (enc([v], 100 + q)[0] for q, v in enumerate((ntrain // 2, 0, (1 << nb) - 1, 1)))
     zero = K.encrypt_bits(np.array([0]), 2.0**-15, 200)[0]
     st = {{}}
+    if os.environ.get("KNN_QUERIES"):
+        # the reference's loop over test records (src/KNN_medical_data.cpp:676-691), dealt over the ranks BY QUERY
+        tests = [test, [0, 2, 45, 0], [0, 21, 36, 1]]
+        e_tests = np.stack([enc(t, 1 + 500 * q) for q, t in enumerate(tests)])     # record 0 = the single-decision test record
+        res = Cc.knn_decisions_batched(OracleKey(), Cc.KnnPlan(nb, ncol, ntrain), e_tests, e_train, thr, az, ao, lo, zero, rank, world, red, st)
+        dec = lambda recs: int("".join("1" if b else "0" for b in K.decrypt_bits(recs)), 2)
+        h = lambda q: hashlib.sha256(b"".join(np.ascontiguousarray(res[k][q]).tobytes() for k in ("decision", "count", "sorted_dists", "dists"))).hexdigest()
+        print(json.dumps(dict(rank=rank, queries=st["my_queries"], sha=[h(q) for q in range(len(tests))],
+                              dists=[[dec(d) for d in res["dists"][q]] for q in range(len(tests))],
+                              sorted=[[dec(d) for d in res["sorted_dists"][q]] for q in range(len(tests))],
+                              count=[dec(res["count"][q]) for q in range(len(tests))],
+                              decision=[bool(K.decrypt_bits(res["decision"][q][None])[0]) for q in range(len(tests))])), flush=True)
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        sys.exit(0)
     res = Cc.knn_decision_sharded(OracleKey(), Cc.KnnPlan(nb, ncol, ntrain), e_test, e_train, thr, az, ao, lo, zero, rank, world, red, st)
     dec = lambda recs: int("".join("1" if b else "0" for b in K.decrypt_bits(recs)), 2)
     h = hashlib.sha256(b"".join(np.ascontiguousarray(res[k]).tobytes() for k in ("decision", "count", "sorted_dists", "dists"))).hexdigest()
@@ -63,13 +78,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run(tmp_path, world):
+def run(tmp_path, world, **extra_env):
     script = tmp_path / f"knn_rank_w{world}.py"
     script.write_text(textwrap.dedent(SCRIPT.format(tests=os.path.join(ROOT, "tests"), pkg=os.path.join(ROOT, "torus-fhe_amd"))))
     port = free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="3")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="3", **extra_env)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for pr in procs:
@@ -88,3 +103,21 @@ def test_knn_two_gloo_ranks_equal_single_rank(tmp_path):
     for o in two:
         assert o["sha"] == one["sha"], "sharded evaluation differs from the single-rank ciphertexts"
         assert (o["dists"], o["sorted"], o["count"], o["decision"]) == (one["dists"], one["sorted"], one["count"], one["decision"])
+
+
+def test_knn_queries_dealt_over_two_gloo_ranks(tmp_path):
+    """thfhe.circuits.knn_decisions_batched: three test records as instances of one DAG pair, dealt over the ranks by query.  Two gloo
+    ranks must return, on every rank, the ciphertexts of the single-rank batch; record 0 must carry the very ciphertexts of the
+    single-decision path (knn_decision_sharded), and every record the plaintext KNN answer."""
+    train = [[1, 20, 35, 1], [2, 3, 44, 0], [3, 16, 41, 1]]
+    tests = [[0, 17, 40, 1], [0, 2, 45, 0], [0, 21, 36, 1]]
+    single_decision = run(tmp_path, 1)[0]
+    one = run(tmp_path, 1, KNN_QUERIES="1")[0]
+    two = run(tmp_path, 2, KNN_QUERIES="1")
+    assert one["sha"][0] == single_decision["sha"], "instance 0 of the batch differs from the single-decision evaluation"
+    for q, t in enumerate(tests):
+        d = [abs(t[1] - r[1]) + abs(t[2] - r[2]) for r in train]
+        assert one["dists"][q] == d and one["sorted"][q] == sorted(d) and one["count"][q] == 2 and one["decision"][q] is True
+    assert sorted(sum((o["queries"] for o in two), [])) == [0, 1, 2] and [o["queries"] for o in sorted(two, key=lambda o: o["rank"])] == [[0, 2], [1]]
+    for o in two:
+        assert o["sha"] == one["sha"], "by-query sharding differs from the single-rank batch"

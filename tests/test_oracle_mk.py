@@ -64,6 +64,8 @@ def test_mk_gates_truth_tables_and_noise(O, mk2):
         assert np.abs(noise).max() < 0.125 and np.abs(noise).max() < 4 * ref.std()
     out = orc.gates(O.AND3, ca[:4], cb[:4], cc[:4])
     assert np.array_equal(K.decrypt_bits(out), (a & b & c)[:4].astype(bool))
+    # the reference's gate as written (J/3gen_mk_gates.jl:55-64): three false operands -> phase -1/4 - 3/8 = +3/8 (mod 1) -> TRUE
+    assert bool(K.decrypt_bits(orc.gates(O.AND3, ca[7:8], cb[7:8], cc[7:8]))[0])
     out = orc.gates(O.MUX, ca[:4], cb[:4], cc[:4])                        # J/3gen_mk_gates.jl:133-150
     assert np.array_equal(K.decrypt_bits(out), np.where(a == 1, b, c)[:4].astype(bool))
     assert np.array_equal(orc.gates(O.NOT, ca), (-ca.astype(np.int64) % 2**32).astype(np.uint32).view(np.int32))

@@ -18,6 +18,7 @@ K = keygen.SecretKeySet(p, seed=1)
 ck = thfhe.CloudKey(p, K.bk, K.ksk)
 COOP = os.environ.get("STAMP_KERNEL", "ring") == "coop"
 ck.set_coop_threshold(1 << 20 if COOP else 0)
+ck.set_ring4_threshold(0)
 rng = np.random.default_rng(0)
 xa, xb = K.encrypt(rng.integers(0, 2, B), 1), K.encrypt(rng.integers(0, 2, B), 2)
 da, db, do = ck.device_records(B), ck.device_records(B), ck.device_records(B)

@@ -8,6 +8,10 @@ from thfhe import keygen
 p = thfhe.make_params("SK-128")
 K = keygen.SecretKeySet(p, seed=1)
 ck = thfhe.CloudKey(p, K.bk, K.ksk)
+if os.environ.get("COOP_MAX"):     # kernel-choice thresholds (A/B runs): rotations up to COOP_MAX -> cooperative kernel, up to RING4_MAX -> four-wave ring
+    ck.set_coop_threshold(int(os.environ["COOP_MAX"]))
+if os.environ.get("RING4_MAX"):
+    ck.set_ring4_threshold(int(os.environ["RING4_MAX"]))
 for B in [int(x) for x in sys.argv[1:]] or [4096]:
     rng = np.random.default_rng(0)
     xa, xb = K.encrypt(rng.integers(0, 2, B), 1), K.encrypt(rng.integers(0, 2, B), 2)

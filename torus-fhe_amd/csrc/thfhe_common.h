@@ -88,9 +88,12 @@ __device__ __forceinline__ void wave_fft_inv(int lane, cplx (&z)[8], cplx *xb, c
 }
 // ---- LDS key ring (shared by the single-key and multi-key ring kernels) --------------------------------------------
 // One LDS-DMA of this wave's 1 KiB slice of a key chunk: lane l fetches 16 B at gptr_lane into LDS at lds_byte_off + 16 l.
-// Inline asm on purpose: the compiler then neither waits vmcnt(0) before every ring read nor reorders the hand-off.
+// Inline asm on purpose: the compiler then neither waits vmcnt(0) before every ring read nor reorders the hand-off.  The LDS base
+// travels in m0 as a register-constrained INPUT ("{m0}"): the compiler itself materialises the value in m0 and knows it is live there,
+// so nothing is clobbered behind its back (round 3 wrote m0 inside the asm and listed it as a clobber, which LLVM calls undefined
+// for a reserved register).  s_nop 0 = the one wait state gfx9 wants between an SALU write of m0 and an LDS-DMA.
 __device__ __forceinline__ void ring_dma(const cplx *gptr_lane, uint32_t lds_byte_off) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds_byte_off) : "memory", "m0");
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "{m0}"(lds_byte_off) : "memory");
 }
 template <int VM>
 __device__ __forceinline__ void ring_barrier() {

@@ -15,28 +15,39 @@
 namespace {
 using namespace thfhe;
 
-// gate-DAG executor plumbing: wires live in one device table [n_wires][words]; a level's operands are gathered into the
-// contiguous staging arrays the bootstrap kernels read, its outputs scattered back
+// gate-DAG executor plumbing.  Wires live in one device table [instances][n_wires][words]: `instances` independent evaluations of
+// the same gate list (the reference's loop over test records around one circuit, src/KNN_medical_data.cpp:676-691).  The gates of a
+// level are numbered G = q * cnt + g (instance q, gate g of the level); a launch handles the slice [first, first + total) of them: its
+// operands are gathered into the contiguous staging arrays the bootstrap kernels read, its outputs scattered back.
 __global__ __launch_bounds__(256) void dag_gather_kernel(const int32_t *__restrict__ wires, const int32_t *__restrict__ idx, int32_t *__restrict__ dst,
-                                                         long count, int words) {
-    const long g = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (g < count && i < words) dst[g * words + i] = wires[(size_t)idx[g] * words + i];
+                                                         long first, long total, long cnt, size_t n_wires, int words,
+                                                         const int32_t *__restrict__ ops, int32_t *__restrict__ ops_out) {
+    const long j = blockIdx.x;
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (j >= total || i >= words) return;
+    const long G = first + j, q = G / cnt, g = G - q * cnt;
+    dst[j * words + i] = wires[((size_t)q * n_wires + idx[g]) * words + i];
+    if (ops_out && i == 0) ops_out[j] = ops[g];   // per-gate opcodes of the slice, in staging order
 }
 __global__ __launch_bounds__(256) void dag_scatter_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int32_t *__restrict__ wires,
-                                                          long count, int words) {
-    const long g = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (g < count && i < words) wires[(size_t)idx[g] * words + i] = src[g * words + i];
+                                                          long first, long total, long cnt, size_t n_wires, int words) {
+    const long j = blockIdx.x;
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (j >= total || i >= words) return;
+    const long G = first + j, q = G / cnt, g = G - q * cnt;
+    wires[((size_t)q * n_wires + idx[g]) * words + i] = src[j * words + i];
 }
-// NOT / COPY gates of one sub-level (no gate of the launch reads another's output)
+// NOT / COPY gates of one sub-level (no gate of the launch reads another's output), every instance
 __global__ __launch_bounds__(256) void dag_wire_linear_kernel(int32_t *__restrict__ wires, const int32_t *__restrict__ in_idx,
-                                                              const int32_t *__restrict__ out_idx, const int32_t *__restrict__ ops, long count, int words) {
-    const long g = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (g >= count || i >= words) return;
-    const uint32_t v = (uint32_t)wires[(size_t)in_idx[g] * words + i];
-    wires[(size_t)out_idx[g] * words + i] = (int32_t)(ops[g] == THFHE_NOT ? 0u - v : v);
+                                                              const int32_t *__restrict__ out_idx, const int32_t *__restrict__ ops, long total, long cnt,
+                                                              size_t n_wires, int words) {
+    const long G = blockIdx.x;
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (G >= total || i >= words) return;
+    const long q = G / cnt, g = G - q * cnt;
+    const size_t base = (size_t)q * n_wires;
+    const uint32_t v = (uint32_t)wires[(base + in_idx[g]) * words + i];
+    wires[(base + out_idx[g]) * words + i] = (int32_t)(ops[g] == THFHE_NOT ? 0u - v : v);
 }
 
 
@@ -112,6 +123,91 @@ int dag_plan(const int32_t *gates, size_t n_inputs, size_t n_gates, Classify cla
         for (size_t q = 0; q < lin[d].size(); q++) emit(d, (int32_t)q + 1, 2, lin[d][q]);
     }
     return THFHE_OK;
+}
+
+// Device buffers of the executor (grow-only, owned by the engine's context and reused by every run on it).
+struct DagBuffers {
+    size_t cap_wires = 0, cap_tab = 0, cap_ops = 0, cap_pack = 0;   // bytes
+    int32_t *d_wires = nullptr, *d_tab = nullptr, *d_ops = nullptr, *d_pack = nullptr;
+    static hipError_t grow(int32_t *&p, size_t &cap, size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        (void)hipFree(p);
+        p = nullptr, cap = 0;
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() {
+        for (int32_t **p : {&d_wires, &d_tab, &d_ops, &d_pack}) (void)hipFree(*p), *p = nullptr;
+        cap_wires = cap_tab = cap_ops = cap_pack = 0;
+    }
+};
+
+// Device-resident executor.  Level by level, each class of a level as slices of at most `slice_cap` gates over ALL instances: gather ->
+// run(cls, d_ops, n) (the engine's prologue + blind rotations + key switch from its staging arrays stage_in[0..2] into stage_out) ->
+// scatter.  Nothing synchronises with the host between levels.
+//   h_inputs  int32[instances][n_inputs][words]
+//   h_sel     wire ids to return (n_sel of them) or null = every gate wire [n_inputs, n_wires)
+//   h_out     int32[instances][n_sel or n_gates][words]
+// ensure(max_gates_per_slice) sizes the engine's workspace and staging and returns its staging pointers through the out-parameters.
+template <typename Ensure, typename Run>
+int dag_execute(const DagPlan &plan, DagBuffers &B, hipStream_t stream, int words, size_t n_inputs, size_t n_gates, size_t instances,
+                const int32_t *h_inputs, const int32_t *h_sel, size_t n_sel, int32_t *h_out, size_t slice_cap, Ensure ensure, Run run) {
+    const size_t n_wires = n_inputs + n_gates;
+    if (instances == 0 || n_gates == 0) return THFHE_OK;
+    if (n_wires * instances > ((size_t)1 << 40) / (size_t)words) return thfhe_fail(THFHE_E_INVALID, "wire table too large");
+    for (size_t s = 0; s < n_sel; s++)
+        if (h_sel[s] < 0 || (size_t)h_sel[s] >= n_wires) return thfhe_fail(THFHE_E_INVALID, "output wire id out of range");
+    const size_t widest = plan.max_width * instances, slice = widest < slice_cap ? widest : slice_cap;
+    int32_t *stage_in[3] = {nullptr, nullptr, nullptr}, *stage_out = nullptr;
+    int rc = ensure(slice ? slice : 1, stage_in, &stage_out);
+    if (rc) return rc;
+    const size_t rec = (size_t)words * sizeof(int32_t);
+    hipError_t e = DagBuffers::grow(B.d_wires, B.cap_wires, instances * n_wires * rec);
+    if (e == hipSuccess) e = DagBuffers::grow(B.d_tab, B.cap_tab, (plan.tab.size() + n_sel) * sizeof(int32_t));
+    if (e == hipSuccess) e = DagBuffers::grow(B.d_ops, B.cap_ops, (slice ? slice : 1) * sizeof(int32_t));
+    if (e == hipSuccess && h_sel) e = DagBuffers::grow(B.d_pack, B.cap_pack, instances * n_sel * rec);
+    if (e != hipSuccess) return thfhe_fail_hip(e, "gate-DAG executor: device tables");
+    int32_t *const d_wires = B.d_wires, *const d_tab = B.d_tab, *const d_sel = B.d_tab + plan.tab.size();
+    if (n_inputs) e = hipMemcpy2DAsync(d_wires, n_wires * rec, h_inputs, n_inputs * rec, n_inputs * rec, instances, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, plan.tab.data(), plan.tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess && n_sel) e = hipMemcpyAsync(d_sel, h_sel, n_sel * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    rc = e == hipSuccess ? THFHE_OK : thfhe_fail_hip(e, "gate-DAG executor: upload");
+    const unsigned wb = (unsigned)((words + 255) / 256);
+    const dim3 block(256);
+    for (size_t b = 0; b < plan.batches.size() && rc == THFHE_OK; b++) {
+        const long cnt = (long)plan.batches[b].count, all = cnt * (long)instances;
+        const int cls = plan.batches[b].cls;
+        const int32_t *t_ops = d_tab + plan.batches[b].off, *t0 = t_ops + cnt, *t1 = t0 + cnt, *t2 = t1 + cnt, *t_out = t2 + cnt;
+        if (cls == 2) {
+            hipLaunchKernelGGL(dag_wire_linear_kernel, dim3((unsigned)all, wb), block, 0, stream, d_wires, t0, t_out, t_ops, all, cnt, n_wires, words);
+            continue;
+        }
+        for (long first = 0; first < all && rc == THFHE_OK; first += (long)slice) {
+            const long n = all - first < (long)slice ? all - first : (long)slice;
+            const dim3 grid((unsigned)n, wb);
+            hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, stream, d_wires, t0, stage_in[0], first, n, cnt, n_wires, words, t_ops, B.d_ops);
+            hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, stream, d_wires, t1, stage_in[1], first, n, cnt, n_wires, words, nullptr, nullptr);
+            if (cls != 0) hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, stream, d_wires, t2, stage_in[2], first, n, cnt, n_wires, words, nullptr, nullptr);
+            rc = run(cls, B.d_ops, (size_t)n);
+            if (!rc) hipLaunchKernelGGL(dag_scatter_kernel, grid, block, 0, stream, stage_out, t_out, d_wires, first, n, cnt, n_wires, words);
+        }
+    }
+    if (rc == THFHE_OK) {
+        e = hipGetLastError();
+        if (e == hipSuccess && h_sel && n_sel) {
+            const long all = (long)(n_sel * instances);
+            hipLaunchKernelGGL(dag_gather_kernel, dim3((unsigned)all, wb), block, 0, stream, d_wires, d_sel, B.d_pack, 0L, all, (long)n_sel, n_wires, words, nullptr, nullptr);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(h_out, B.d_pack, instances * n_sel * rec, hipMemcpyDeviceToHost, stream);
+        } else if (e == hipSuccess && !h_sel) {
+            e = hipMemcpy2DAsync(h_out, n_gates * rec, d_wires + n_inputs * (size_t)words, n_wires * rec, n_gates * rec, instances, hipMemcpyDeviceToHost, stream);
+        }
+        if (e != hipSuccess) rc = thfhe_fail_hip(e, "gate-DAG executor");
+    }
+    e = hipStreamSynchronize(stream);
+    if (rc == THFHE_OK && e != hipSuccess) rc = thfhe_fail_hip(e, "gate-DAG executor: sync");
+    return rc;
 }
 
 }  // namespace

@@ -833,6 +833,8 @@ struct thfhe_mk_ctx {
     size_t cap_jobs = 0;
     int32_t *d_bara = nullptr, *d_barb = nullptr, *d_u = nullptr, *d_tmp = nullptr;
     size_t cap_stage = 0;
+    DagBuffers dag;   // gate-DAG executor tables (thfhe_dag.h)
+    size_t dag_slice = 8192;  // gates per launch of a DAG level
     int32_t *d_in[3] = {nullptr, nullptr, nullptr};
     int32_t *d_out = nullptr;
     bool profiling = false, ev_valid = false;
@@ -1240,6 +1242,7 @@ void thfhe_mk_ctx_destroy(thfhe_mk_ctx *c) {
     (void)hipFree(c->d_acc);
     for (auto &p : c->d_in) (void)hipFree(p);
     (void)hipFree(c->d_out);
+    c->dag.release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1325,10 +1328,12 @@ int thfhe_mk_gates(thfhe_mk_ctx *c, int op, const int32_t *in0, const int32_t *i
 }
 
 // Gate-DAG evaluation for the 3-gen scheme: the reference's integer circuits (mk_add_3gen ... mk_int_mul_3gen, J/3gen_mk_gates.jl:183-362) as
-// ASAP levels, wires resident in HBM (thfhe_dag.h).  Classes: two-input gates NAND / OR / AND / XOR with per-gate opcodes in one launch,
-// AND3, MUX (two ANDs + linear combine, :133-150), NOT / COPY (mk_gate_not_3gen, mk_copy_3gen: no bootstrap).
-int thfhe_mk_dag_run(thfhe_mk_ctx *c, int32_t *wires, size_t n_inputs, const int32_t *gates, size_t n_gates, int64_t *stats) {
-    if (!c || !wires || (!gates && n_gates)) return thfhe_fail(THFHE_E_INVALID, "null argument");
+// ASAP levels, wires resident in HBM (thfhe_dag.h), `instances` independent evaluations side by side.  Classes: two-input gates NAND / OR /
+// AND / XOR with per-gate opcodes in one launch, AND3, MUX (two ANDs + linear combine, :133-150), NOT / COPY (mk_gate_not_3gen,
+// mk_copy_3gen: no bootstrap).
+int thfhe_mk_dag_run_batch(thfhe_mk_ctx *c, const int32_t *inputs, size_t n_inputs, const int32_t *gates, size_t n_gates, size_t instances,
+                           const int32_t *out_wires, size_t n_out, int32_t *outputs, int64_t *stats) {
+    if (!c || (!inputs && n_inputs) || (!gates && n_gates) || (!outputs && n_gates) || (!out_wires && n_out)) return thfhe_fail(THFHE_E_INVALID, "null argument");
     DagPlan plan;
     int rc = dag_plan(gates, n_inputs, n_gates,
                       [](int op) {
@@ -1337,52 +1342,35 @@ int thfhe_mk_dag_run(thfhe_mk_ctx *c, int32_t *wires, size_t n_inputs, const int
                       plan);
     if (rc) return rc;
     if (stats) plan.fill_stats(stats);
-    if (n_gates == 0) return THFHE_OK;
-    const size_t n_wires = n_inputs + n_gates;
     std::lock_guard<std::mutex> lk(c->mu);
     THFHE_HIP(hipSetDevice(c->device));
     const int words = c->words + 1;
-    rc = mk_ensure_workspace(c, plan.max_rot ? plan.max_rot : 1);
-    if (!rc) rc = mk_ensure_stage(c, plan.max_width * words);
-    if (rc) return rc;
-    int32_t *d_wires = nullptr, *d_tab = nullptr;
-    hipError_t e = hipMalloc(&d_wires, n_wires * (size_t)words * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_tab, plan.tab.size() * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_wires, wires, n_inputs * (size_t)words * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, plan.tab.data(), plan.tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
-    rc = e == hipSuccess ? THFHE_OK : thfhe_fail_hip(e, "thfhe_mk_dag_run setup");
-    const unsigned wb = (unsigned)((words + 255) / 256);
     MKLin L;
     mk_gate_lin(THFHE_NAND, 0, L);
-    for (size_t b = 0; b < plan.batches.size() && rc == THFHE_OK; b++) {
-        const long cnt = (long)plan.batches[b].count;
-        const int cls = plan.batches[b].cls;
-        const int32_t *t_ops = d_tab + plan.batches[b].off, *t0 = t_ops + cnt, *t1 = t0 + cnt, *t2 = t1 + cnt, *t_out = t2 + cnt;
-        const dim3 grid(wb, (unsigned)cnt), block(256);
-        if (cls == 2) {
-            hipLaunchKernelGGL(dag_wire_linear_kernel, grid, block, 0, c->stream, d_wires, t0, t_out, t_ops, cnt, words);
-            continue;
-        }
-        hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, c->stream, d_wires, t0, c->d_in[0], cnt, words);
-        hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, c->stream, d_wires, t1, c->d_in[1], cnt, words);
-        if (cls != 0) hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, c->stream, d_wires, t2, c->d_in[2], cnt, words);
-        if (cls == 0)
-            rc = mk_enqueue_bootstraps(c, c->d_in[0], c->d_in[1], nullptr, L, L, 1, (size_t)cnt, (int64_t)1 << 61, c->d_out, t_ops);
-        else
-            rc = mk_gates_dev_locked(c, cls == 1 ? THFHE_MUX : THFHE_AND3, c->d_in[0], c->d_in[1], c->d_in[2], c->d_out, (size_t)cnt);
-        if (!rc) hipLaunchKernelGGL(dag_scatter_kernel, grid, block, 0, c->stream, c->d_out, t_out, d_wires, cnt, words);
-    }
-    if (rc == THFHE_OK) {
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(wires + n_inputs * (size_t)words, d_wires + n_inputs * (size_t)words, n_gates * (size_t)words * sizeof(int32_t),
-                                                hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess) rc = thfhe_fail_hip(e, "thfhe_mk_dag_run");
-    }
-    e = hipStreamSynchronize(c->stream);
-    if (rc == THFHE_OK && e != hipSuccess) rc = thfhe_fail_hip(e, "thfhe_mk_dag_run sync");
-    (void)hipFree(d_wires);
-    (void)hipFree(d_tab);
-    return rc;
+    return dag_execute(
+        plan, c->dag, c->stream, words, n_inputs, n_gates, instances, inputs, out_wires, n_out, outputs, c->dag_slice,
+        [&](size_t max_gates, int32_t **in, int32_t **out) {
+            int r = mk_ensure_workspace(c, 2 * max_gates);
+            if (!r) r = mk_ensure_stage(c, max_gates * words);
+            in[0] = c->d_in[0], in[1] = c->d_in[1], in[2] = c->d_in[2], *out = c->d_out;
+            return r;
+        },
+        [&](int cls, const int32_t *d_ops, size_t n) {
+            if (cls == 0) return mk_enqueue_bootstraps(c, c->d_in[0], c->d_in[1], nullptr, L, L, 1, n, (int64_t)1 << 61, c->d_out, d_ops);
+            return mk_gates_dev_locked(c, cls == 1 ? THFHE_MUX : THFHE_AND3, c->d_in[0], c->d_in[1], c->d_in[2], c->d_out, n);
+        });
+}
+
+int thfhe_mk_set_dag_slice(thfhe_mk_ctx *c, size_t max_gates) {
+    if (!c || max_gates < 1 || max_gates > 32767) return thfhe_fail(THFHE_E_INVALID, "slice must be 1 .. 32767 gates");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->dag_slice = max_gates;
+    return THFHE_OK;
+}
+
+int thfhe_mk_dag_run(thfhe_mk_ctx *c, int32_t *wires, size_t n_inputs, const int32_t *gates, size_t n_gates, int64_t *stats) {
+    if (!wires) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    return thfhe_mk_dag_run_batch(c, wires, n_inputs, gates, n_gates, 1, nullptr, 0, wires + n_inputs * (size_t)(c ? c->words + 1 : 0), stats);
 }
 
 int thfhe_mk_gates_mixed(thfhe_mk_ctx *c, const int32_t *ops, const int32_t *in0, const int32_t *in1, int32_t *out, size_t count) {

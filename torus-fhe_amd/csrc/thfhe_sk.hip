@@ -153,18 +153,22 @@ struct BRArgs {
 #ifndef THFHE_RING_NF
 #define THFHE_RING_NF 16
 #endif
-template <int L, int V = 1>
-__global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) {
-    __shared__ __attribute__((aligned(4096))) int32_t sAcc[8][2048];   // rotated_digits_z ORs byte offsets into the polynomial base
-    __shared__ cplx sX[8][kXbufSlots];
+// W = waves (= jobs) per workgroup.  W = 8 is the throughput shape described above.  W = 4 (one wave per SIMD, 92 KiB of LDS, each wave
+// brings TWO slices of a chunk) is the shape for batches that cannot give every CU eight jobs (<= 1024 rotations): a wave alone on its
+// SIMD issues at ~87 % of what a pair reaches together (tools/probes/issue_probe.hip), so four jobs finish much sooner than eight.
+template <int L, int V = 1, int W = 8>
+__global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void sk_blind_rotate_ring_kernel(BRArgs a) {
+    __shared__ __attribute__((aligned(4096))) int32_t sAcc[W][2048];   // rotated_digits_z ORs byte offsets into the polynomial base
+    __shared__ cplx sX[W][kXbufSlots];
     __shared__ cplx sRing[3][512];
     constexpr int ROWS = 2 * L;
+    constexpr int DPC = 8 / W;   // ring DMAs per wave and chunk
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
     const LaneRoots roots{a.tw[576 + 2 * lane], a.tw[576 + 2 * lane + 1]};
     const LaneTw tw = make_lane_tw(roots);
-    const long job = (long)blockIdx.x * 8 + wave;
+    const long job = (long)blockIdx.x * W + wave;
     const bool has_job = job < a.jobs;
     int32_t *acc = sAcc[wave];
     cplx *xb = sX[wave];
@@ -173,12 +177,13 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
     if (has_job) acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
 
     const long total_chunks = (long)a.n * ROWS * 4;
-    const cplx *gsrc = a.bk + wave * 64 + lane;
+    const cplx *gsrc = a.bk + wave * (64 * DPC) + lane;
     long q_issue = 0;
     int slot_issue = 0;
-    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sRing[0][0] + (uint32_t)wave * 1024u;
+    const uint32_t ring_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sRing[0][0] + (uint32_t)wave * (1024u * DPC);
     auto issue = [&]() {
-        ring_dma(gsrc, ring_base + (uint32_t)slot_issue * 8192u);
+#pragma unroll
+        for (int d = 0; d < DPC; d++) ring_dma(gsrc + 64 * d, ring_base + (uint32_t)slot_issue * 8192u + 1024u * d);
         if (q_issue + 1 < total_chunks) {
             gsrc += 512;
             q_issue++;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
             cplx bA[4], bB[4];
 #pragma unroll
             for (int c4 = 0; c4 < 4; c4++) {
-                if (c4 == 0) ring_barrier<2>(); else ring_barrier<1>();
+                if (c4 == 0) ring_barrier<2 * DPC>(); else ring_barrier<DPC>();
                 STAMP(1);
                 if (c4 > 0) issue();
                 const cplx *B = &sRing[slot_use][0];
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_ring_kernel(BRArgs a) 
                 slot_use = slot_use == 2 ? 0 : slot_use + 1;
                 STAMP(2);
             }
-            ring_barrier<2>();  // the row's last chunk is read by all (its second half sits in bB): refill its slot before the next transform
+            ring_barrier<2 * DPC>();  // the row's last chunk is read by all (its second half sits in bB): refill its slot before the next transform
             issue();
             STAMP(1);
             if (active) {
@@ -626,7 +631,8 @@ struct thfhe_ctx {
     int32_t *d_ksk = nullptr; // padded rows
     int ks_w = 0;             // words per lane of a padded KSK row
     long ks_multi_min_gates = 1024;  // batches of at least this many gates use sk_keyswitch_multi_kernel (rows shared by the gates of a workgroup)
-    int coop_max_jobs = 1024;  // batches up to this many rotations use the cooperative (latency) kernel (measured crossover ~1150)
+    int coop_max_jobs = 768;    // remainders (batch mod 2048) up to this many rotations use the cooperative (latency) kernel
+    int ring4_max_jobs = 1024;  // ... above it and up to this many, the four-wave ring kernel (launch_br)
     cplx *d_tw = nullptr;
     // workspace
     size_t cap_jobs = 0;
@@ -637,8 +643,8 @@ struct thfhe_ctx {
     int32_t *d_in[3] = {nullptr, nullptr, nullptr};
     int32_t *d_out = nullptr;
     // gate-DAG executor: wire table and index tables (grow-only, reused by every thfhe_dag_run on this context)
-    size_t cap_wires = 0, cap_tab = 0;
-    int32_t *d_wires = nullptr, *d_tab = nullptr;
+    DagBuffers dag;
+    size_t dag_slice = 28672;  // gates per launch of a DAG level: 14 x 2048, so that a MUX slice (2 rotations per gate) stays under the 65 535 limit of the prologue's grid
     // profiling
     bool profiling = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -677,19 +683,23 @@ int ensure_stage(thfhe_ctx *c, size_t words) {
     return THFHE_OK;
 }
 
+// One launch of `a.jobs` rotations on one kernel shape.
 template <int L>
-void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
-    // small batches: cooperative latency kernel (one workgroup per gate); large ones: LDS-ring kernel (eight gates per workgroup)
-    if (a.jobs <= coop_max) {
+void launch_coop(const BRArgs &a, hipStream_t s) {
 #ifdef THFHE_VARIANTS
-        static const int pace = std::getenv("THFHE_COOP_PACE") ? std::atoi(std::getenv("THFHE_COOP_PACE")) : 1;
-        if (pace == 0) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 0>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
-        if (pace == 2) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 2>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
-        if (pace == 4) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 4>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
+    static const int pace = std::getenv("THFHE_COOP_PACE") ? std::atoi(std::getenv("THFHE_COOP_PACE")) : 1;
+    if (pace == 0) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 0>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
+    if (pace == 2) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 2>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
+    if (pace == 4) { hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 4>), dim3((unsigned)a.jobs), dim3(512), 0, s, a); return; }
 #endif
-        hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 1>), dim3((unsigned)a.jobs), dim3(512), 0, s, a);
-        return;
-    }
+    hipLaunchKernelGGL((sk_blind_rotate_coop_kernel<L, 1>), dim3((unsigned)a.jobs), dim3(512), 0, s, a);
+}
+template <int L>
+void launch_ring4(const BRArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 1, 4>), dim3((unsigned)((a.jobs + 3) / 4)), dim3(256), 0, s, a);
+}
+template <int L>
+void launch_ring8(const BRArgs &a, hipStream_t s) {
     const dim3 grid((unsigned)((a.jobs + 7) / 8)), block(512);
 #ifdef THFHE_VARIANTS  // developer A/B builds only: 8 = first transpose through the LDS (variant "r")
     static const int variant = std::getenv("THFHE_RING_VARIANT") ? std::atoi(std::getenv("THFHE_RING_VARIANT")) : 0;
@@ -697,6 +707,33 @@ void launch_br(const BRArgs &a, hipStream_t s, int coop_max) {
     if (variant == 3) { hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 3>), grid, block, 0, s, a); return; }   // forward in registers, inverse through the LDS
 #endif
     hipLaunchKernelGGL((sk_blind_rotate_ring_kernel<L, 1>), grid, block, 0, s, a);
+}
+
+// Kernel choice for a batch of rotations.  Measured on one MI355X (256 CUs, SK-128; profiles/r04_time_batch.txt): a round of the
+// eight-wave ring kernel takes 14.9 ms whether its workgroups hold 1 025 or 2 048 jobs between them, a round of the four-wave shape
+// 9.8 ms for up to 1 024 jobs, the cooperative kernel 3.0 ms per 256 jobs.  So a batch is cut into whole rounds of 2 048 jobs on the
+// eight-wave kernel plus a remainder r on the cheapest shape: cooperative up to coop_max (default 768: 8.6 ms), four-wave ring up to
+// ring4_max (1 024), four-wave ring + one cooperative round up to ring4_max + 256 (12.9 ms), else one more eight-wave round.
+// (3 072 rotations: 30.1 ms as one launch of 384 eight-wave workgroups, 24.8 ms as 2 048 + 1 024.)  The pieces are independent jobs
+// on disjoint slices of the same arrays, launched back to back on the context's stream.
+template <int L>
+void launch_br(const BRArgs &a, hipStream_t s, int coop_max, int ring4_max) {
+    auto piece = [&](long first, long count) {
+        BRArgs b = a;
+        b.bara += first * a.n_pad, b.barb += first, b.out += first * 1025, b.jobs = count;
+        return b;
+    };
+    constexpr long kRound = 2048;   // 256 CUs x 8 jobs
+    const long full = (coop_max > 0 || ring4_max > 0) ? a.jobs / kRound * kRound : a.jobs;   // both thresholds 0: everything on the eight-wave kernel
+    if (full > 0) launch_ring8<L>(piece(0, full), s);
+    const long r = a.jobs - full;
+    if (r == 0) return;
+    if (r <= coop_max) launch_coop<L>(piece(full, r), s);
+    else if (r <= ring4_max) launch_ring4<L>(piece(full, r), s);
+    else if (ring4_max > 0 && coop_max > 0 && r <= ring4_max + (coop_max < 256 ? coop_max : 256)) {
+        launch_ring4<L>(piece(full, ring4_max), s);
+        launch_coop<L>(piece(full + ring4_max, r - ring4_max), s);
+    } else launch_ring8<L>(piece(full, r), s);
 }
 
 // rotations (prologue + blind rotate) of `jobs` = gates * rot_per_gate jobs into c->d_u
@@ -713,10 +750,10 @@ int enqueue_rotations(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[1], c->stream));
     BRArgs a{c->d_bk, c->d_tw, c->d_bara, c->d_barb, c->d_u, (long)jobs, n, c->n_pad, c->p.Bgbit, mu};
     switch (c->p.l) {
-    case 1: launch_br<1>(a, c->stream, c->coop_max_jobs); break;
-    case 2: launch_br<2>(a, c->stream, c->coop_max_jobs); break;
-    case 3: launch_br<3>(a, c->stream, c->coop_max_jobs); break;
-    case 4: launch_br<4>(a, c->stream, c->coop_max_jobs); break;
+    case 1: launch_br<1>(a, c->stream, c->coop_max_jobs, c->ring4_max_jobs); break;
+    case 2: launch_br<2>(a, c->stream, c->coop_max_jobs, c->ring4_max_jobs); break;
+    case 3: launch_br<3>(a, c->stream, c->coop_max_jobs, c->ring4_max_jobs); break;
+    case 4: launch_br<4>(a, c->stream, c->coop_max_jobs, c->ring4_max_jobs); break;
     default: return thfhe_fail(THFHE_E_UNSUPPORTED, "decomposition length l must be 1..4");
     }
     if (c->profiling) THFHE_HIP(hipEventRecord(c->ev[2], c->stream));
@@ -869,8 +906,7 @@ void thfhe_ctx_destroy(thfhe_ctx *c) {
     (void)hipFree(c->d_u);
     for (auto &p : c->d_in) (void)hipFree(p);
     (void)hipFree(c->d_out);
-    (void)hipFree(c->d_wires);
-    (void)hipFree(c->d_tab);
+    c->dag.release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -927,6 +963,12 @@ int thfhe_set_coop_threshold(thfhe_ctx *c, int max_jobs) {
     if (!c || max_jobs < 0) return thfhe_fail(THFHE_E_INVALID, "bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     c->coop_max_jobs = max_jobs;
+    return THFHE_OK;
+}
+int thfhe_set_ring4_threshold(thfhe_ctx *c, int max_jobs) {
+    if (!c || max_jobs < 0) return thfhe_fail(THFHE_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->ring4_max_jobs = max_jobs;
     return THFHE_OK;
 }
 int thfhe_set_profiling(thfhe_ctx *c, int enabled) {
@@ -995,68 +1037,47 @@ int thfhe_gates_mixed(thfhe_ctx *c, const int32_t *ops, const int32_t *in0, cons
 }
 
 // Gate-DAG evaluation: ASAP levelising scheduler (thfhe_dag.h) + device-resident executor.  The reference's
-// applications issue these gates as sequential boots* calls (src/KNN_medical_data.cpp:127-489); here every level is one blind-rotate
-// launch per gate class, the wire table stays in HBM and nothing synchronises with the host between levels.
-int thfhe_dag_run(thfhe_ctx *c, int32_t *wires, size_t n_inputs, const int32_t *gates, size_t n_gates, int64_t *stats) {
-    if (!c || !wires || (!gates && n_gates)) return thfhe_fail(THFHE_E_INVALID, "null argument");
+// applications issue these gates as sequential boots* calls (src/KNN_medical_data.cpp:127-489), once per test record (:676-691); here
+// every level is one blind-rotate launch per gate class over ALL instances, the wire tables stay in HBM and nothing synchronises with
+// the host between levels.
+int thfhe_dag_run_batch(thfhe_ctx *c, const int32_t *inputs, size_t n_inputs, const int32_t *gates, size_t n_gates, size_t instances,
+                        const int32_t *out_wires, size_t n_out, int32_t *outputs, int64_t *stats) {
+    if (!c || (!inputs && n_inputs) || (!gates && n_gates) || (!outputs && n_gates) || (!out_wires && n_out)) return thfhe_fail(THFHE_E_INVALID, "null argument");
     DagPlan plan;
     int rc = dag_plan(gates, n_inputs, n_gates, [](int op) { return op == THFHE_NOT || op == THFHE_COPY ? 2 : (op == THFHE_MUX ? 1 : (op >= THFHE_NAND && op <= THFHE_ORYN ? 0 : -1)); },
                       plan);
     if (rc) return rc;
     if (stats) plan.fill_stats(stats);
-    if (n_gates == 0) return THFHE_OK;
-    const size_t n_wires = n_inputs + n_gates;
     std::lock_guard<std::mutex> lk(c->mu);
     THFHE_HIP(hipSetDevice(c->device));
     const int words = c->p.n + 1;
-    rc = ensure_workspace(c, plan.max_rot ? plan.max_rot : 1);
-    if (!rc) rc = ensure_stage(c, plan.max_width * words);
-    if (rc) return rc;
-    const size_t wbytes = n_wires * (size_t)words * sizeof(int32_t), tbytes = plan.tab.size() * sizeof(int32_t);
-    hipError_t e = hipSuccess;
-    if (wbytes > c->cap_wires) {
-        (void)hipFree(c->d_wires);
-        c->d_wires = nullptr, c->cap_wires = 0;
-        e = hipMalloc(&c->d_wires, wbytes);
-        if (e == hipSuccess) c->cap_wires = wbytes;
-    }
-    if (e == hipSuccess && tbytes > c->cap_tab) {
-        (void)hipFree(c->d_tab);
-        c->d_tab = nullptr, c->cap_tab = 0;
-        e = hipMalloc(&c->d_tab, tbytes);
-        if (e == hipSuccess) c->cap_tab = tbytes;
-    }
-    int32_t *const d_wires = c->d_wires, *const d_tab = c->d_tab;
-    if (e == hipSuccess) e = hipMemcpyAsync(d_wires, wires, n_inputs * (size_t)words * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, plan.tab.data(), plan.tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
-    rc = e == hipSuccess ? THFHE_OK : thfhe_fail_hip(e, "thfhe_dag_run setup");
-    const unsigned wb = (unsigned)((words + 255) / 256);
-    for (size_t b = 0; b < plan.batches.size() && rc == THFHE_OK; b++) {
-        const long cnt = (long)plan.batches[b].count;
-        const int32_t *t_ops = d_tab + plan.batches[b].off, *t0 = t_ops + cnt, *t1 = t0 + cnt, *t2 = t1 + cnt, *t_out = t2 + cnt;
-        const dim3 grid(wb, (unsigned)cnt), block(256);
-        if (plan.batches[b].cls == 2) {
-            hipLaunchKernelGGL(dag_wire_linear_kernel, grid, block, 0, c->stream, d_wires, t0, t_out, t_ops, cnt, words);
-            continue;
-        }
-        const bool is_mux = plan.batches[b].cls == 1;
-        hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, c->stream, d_wires, t0, c->d_in[0], cnt, words);
-        hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, c->stream, d_wires, t1, c->d_in[1], cnt, words);
-        if (is_mux) hipLaunchKernelGGL(dag_gather_kernel, grid, block, 0, c->stream, d_wires, t2, c->d_in[2], cnt, words);
-        rc = enqueue_rotations(c, is_mux ? THFHE_MUX : THFHE_NAND, c->d_in[0], c->d_in[1], is_mux ? c->d_in[2] : nullptr, (size_t)cnt, is_mux ? 2 : 1,
-                               1 << 29, is_mux ? nullptr : t_ops);
-        if (!rc) rc = enqueue_keyswitch(c, c->d_u, c->d_out, (size_t)cnt, is_mux ? 2 : 1, false);
-        if (!rc) hipLaunchKernelGGL(dag_scatter_kernel, grid, block, 0, c->stream, c->d_out, t_out, d_wires, cnt, words);
-    }
-    if (rc == THFHE_OK) {
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(wires + n_inputs * (size_t)words, d_wires + n_inputs * (size_t)words, n_gates * (size_t)words * sizeof(int32_t),
-                                                hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess) rc = thfhe_fail_hip(e, "thfhe_dag_run");
-    }
-    e = hipStreamSynchronize(c->stream);
-    if (rc == THFHE_OK && e != hipSuccess) rc = thfhe_fail_hip(e, "thfhe_dag_run sync");
-    return rc;
+    return dag_execute(
+        plan, c->dag, c->stream, words, n_inputs, n_gates, instances, inputs, out_wires, n_out, outputs, c->dag_slice,
+        [&](size_t max_gates, int32_t **in, int32_t **out) {
+            int r = ensure_workspace(c, 2 * max_gates);
+            if (!r) r = ensure_stage(c, max_gates * words);
+            in[0] = c->d_in[0], in[1] = c->d_in[1], in[2] = c->d_in[2], *out = c->d_out;
+            return r;
+        },
+        [&](int cls, const int32_t *d_ops, size_t n) {
+            const bool is_mux = cls == 1;
+            int r = enqueue_rotations(c, is_mux ? THFHE_MUX : THFHE_NAND, c->d_in[0], c->d_in[1], is_mux ? c->d_in[2] : nullptr, n, is_mux ? 2 : 1, 1 << 29,
+                                      is_mux ? nullptr : d_ops);
+            if (!r) r = enqueue_keyswitch(c, c->d_u, c->d_out, n, is_mux ? 2 : 1, false);
+            return r;
+        });
+}
+
+int thfhe_set_dag_slice(thfhe_ctx *c, size_t max_gates) {
+    if (!c || max_gates < 1 || max_gates > 32767) return thfhe_fail(THFHE_E_INVALID, "slice must be 1 .. 32767 gates");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->dag_slice = max_gates;
+    return THFHE_OK;
+}
+
+int thfhe_dag_run(thfhe_ctx *c, int32_t *wires, size_t n_inputs, const int32_t *gates, size_t n_gates, int64_t *stats) {
+    if (!wires) return thfhe_fail(THFHE_E_INVALID, "null argument");
+    return thfhe_dag_run_batch(c, wires, n_inputs, gates, n_gates, 1, nullptr, 0, wires + n_inputs * (size_t)(c ? c->p.n + 1 : 0), stats);
 }
 
 int thfhe_bootstrap_wo_keyswitch(thfhe_ctx *c, int32_t mu, const int32_t *x, int32_t *out_N1, size_t count) {

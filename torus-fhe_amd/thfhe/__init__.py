@@ -146,6 +146,9 @@ SIGNATURES = {
     "thfhe_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_gates_mixed": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_dag_run": (C.c_int, [_vp, _i32p, C.c_size_t, _i32p, C.c_size_t, _i64p]),
+    "thfhe_set_dag_slice": (C.c_int, [_vp, C.c_size_t]),
+    "thfhe_mk_set_dag_slice": (C.c_int, [_vp, C.c_size_t]),
+    "thfhe_dag_run_batch": (C.c_int, [_vp, _i32p, C.c_size_t, _i32p, C.c_size_t, C.c_size_t, _i32p, C.c_size_t, _i32p, _i64p]),
     "thfhe_bootstrap": (C.c_int, [_vp, C.c_int32, _i32p, _i32p, C.c_size_t]),
     "thfhe_bootstrap_wo_keyswitch": (C.c_int, [_vp, C.c_int32, _i32p, _i32p, C.c_size_t]),
     "thfhe_keyswitch": (C.c_int, [_vp, _i32p, _i32p, C.c_size_t]),
@@ -157,6 +160,7 @@ SIGNATURES = {
     "thfhe_gates_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
     "thfhe_sync": (C.c_int, [_vp]),
     "thfhe_set_coop_threshold": (C.c_int, [_vp, C.c_int]),
+    "thfhe_set_ring4_threshold": (C.c_int, [_vp, C.c_int]),
     "thfhe_set_profiling": (C.c_int, [_vp, C.c_int]),
     "thfhe_last_timings": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "thfhe_ccs_ctx_create": (C.c_int, [C.POINTER(Params), _i32p, _i32p, _i32p, _i32p, C.c_int, C.POINTER(_vp)]),
@@ -189,6 +193,7 @@ SIGNATURES = {
     "thfhe_mk_gates": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_gates_mixed": (C.c_int, [_vp, _i32p, _i32p, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_dag_run": (C.c_int, [_vp, _i32p, C.c_size_t, _i32p, C.c_size_t, _i64p]),
+    "thfhe_mk_dag_run_batch": (C.c_int, [_vp, _i32p, C.c_size_t, _i32p, C.c_size_t, C.c_size_t, _i32p, C.c_size_t, _i32p, _i64p]),
     "thfhe_mk_bootstrap": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, C.c_size_t]),
     "thfhe_mk_prologue_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_size_t]),
     "thfhe_mk_set_stream": (C.c_int, [_vp, _vp]),
@@ -294,6 +299,21 @@ class DeviceBuffer:
             self.ptr = None
 
 
+def _dag_run_batch(fn, h, words, input_records, gates, out_wires):
+    """Shared body of CloudKey.dag_run_batch / MKCloudKey.dag_run_batch."""
+    x = np.ascontiguousarray(input_records, np.int32)
+    if x.ndim != 3 or x.shape[2] != words:
+        raise ValueError("dag_run_batch: input records must be int32[instances][n_inputs][%d]" % words)
+    g = np.ascontiguousarray(gates, np.int32).reshape(-1, 4)
+    q, n_in = x.shape[0], x.shape[1]
+    sel = None if out_wires is None else np.ascontiguousarray(out_wires, np.int32).reshape(-1)
+    out = np.zeros((q, g.shape[0] if sel is None else sel.shape[0], words), np.int32)
+    st = np.zeros(4, np.int64)
+    _check(fn(h, _p32(x), n_in, _p32(g), g.shape[0], q, _p32(sel), 0 if sel is None else sel.shape[0], _p32(out), st.ctypes.data_as(_i64p)))
+    return out, dict(levels=int(st[0]), launches=int(st[1]), rotations=int(st[2]) * q, widest_level=int(st[3]) * q, instances=q)
+
+
+
 class CloudKey:
     """Single-key evaluation context = the reference's CloudKey (api.jl:215-231): bootstrap key + keyswitch key,
     held on one MI355X in the engine's transformed layout.
@@ -356,6 +376,12 @@ class CloudKey:
         _check(lib().thfhe_dag_run(self.h, _p32(wires), x.shape[0], _p32(g), g.shape[0], st.ctypes.data_as(_i64p)))
         return wires, dict(levels=int(st[0]), launches=int(st[1]), rotations=int(st[2]), widest_level=int(st[3]))
 
+    def dag_run_batch(self, input_records, gates, out_wires=None):
+        """`instances` evaluations of one gate list side by side (thfhe_dag_run_batch; the reference's loop over test records,
+        src/KNN_medical_data.cpp:676-691).  input_records: int32[instances][n_inputs][n+1]; out_wires: wire ids to return (None = every gate
+        wire).  Returns (int32[instances][len(out_wires) or n_gates][n+1], stats)."""
+        return _dag_run_batch(lib().thfhe_dag_run_batch, self.h, self.words, input_records, gates, out_wires)
+
     def bootstrap(self, x, mu=MU8):
         x = _rec(x, self.words)
         out = np.empty_like(x)
@@ -399,15 +425,30 @@ class CloudKey:
     def sync(self):
         _check(lib().thfhe_sync(self.h))
 
+    def set_dag_slice(self, max_gates):
+        """Gates per launch of a DAG level (dag_run_batch cuts wider levels into slices)."""
+        _check(lib().thfhe_set_dag_slice(self.h, int(max_gates)))
+
+    def set_ring4_threshold(self, max_jobs):
+        """Remainders (batch mod 2048) above the cooperative threshold and <= max_jobs rotations use the four-wave ring kernel; 0 disables it."""
+        _check(lib().thfhe_set_ring4_threshold(self.h, int(max_jobs)))
+        self._ring4_threshold = int(max_jobs)
+
     def set_coop_threshold(self, max_jobs):
-        """Batches of <= max_jobs rotations use the cooperative latency kernel; 0 forces the LDS-ring kernel."""
+        """Remainders (batch mod 2048) of <= max_jobs rotations use the cooperative latency kernel; 0 disables it."""
         _check(lib().thfhe_set_coop_threshold(self.h, int(max_jobs)))
         self._coop_threshold = int(max_jobs)
 
     def rotation_kernel_name(self, rotations):
-        """The blind-rotation kernel a batch of `rotations` is dispatched to (thfhe_sk.hip launch logic; for profiles and bench.py)."""
+        """The blind-rotation kernel that does most of a batch of `rotations` (thfhe_sk.hip launch_br; for profiles and bench.py)."""
         l = self.params.l
-        return f"sk_blind_rotate_ring_kernel<{l}>" if rotations > getattr(self, "_coop_threshold", 1024) else f"sk_blind_rotate_coop_kernel<{l}>"
+        coop, ring4 = getattr(self, "_coop_threshold", 768), getattr(self, "_ring4_threshold", 1024)
+        r = rotations % 2048 if (coop or ring4) else 0
+        if rotations >= 2048 or r == 0:
+            return f"sk_blind_rotate_ring_kernel<{l}>"
+        if r <= coop:
+            return f"sk_blind_rotate_coop_kernel<{l}>"
+        return f"sk_blind_rotate_ring_kernel<{l}, 4 waves>" if r <= ring4 + min(coop, 256) and ring4 else f"sk_blind_rotate_ring_kernel<{l}>"
 
     def set_profiling(self, on):
         _check(lib().thfhe_set_profiling(self.h, int(bool(on))))
@@ -506,6 +547,10 @@ class MKCloudKey:
         _check(lib().thfhe_mk_dag_run(self.h, _p32(wires), x.shape[0], _p32(g), g.shape[0], st.ctypes.data_as(_i64p)))
         return wires, dict(levels=int(st[0]), launches=int(st[1]), rotations=int(st[2]), widest_level=int(st[3]))
 
+    def dag_run_batch(self, input_records, gates, out_wires=None):
+        """`instances` evaluations of one 3-gen gate list side by side (thfhe_mk_dag_run_batch)."""
+        return _dag_run_batch(lib().thfhe_mk_dag_run_batch, self.h, self.words, input_records, gates, out_wires)
+
     def bootstrap(self, x, mu=MU8_64):
         x = _rec(x, self.words)
         out = np.empty_like(x)
@@ -538,6 +583,9 @@ class MKCloudKey:
 
     def set_profiling(self, on):
         _check(lib().thfhe_mk_set_profiling(self.h, int(bool(on))))
+
+    def set_dag_slice(self, max_gates):
+        _check(lib().thfhe_mk_set_dag_slice(self.h, int(max_gates)))
 
     def set_pair_threshold(self, max_single_jobs):
         """Batches of <= max_single_jobs rotations run one gate per workgroup; larger ones two gates per workgroup."""

@@ -232,6 +232,57 @@ def knn_decision_sharded(ck, plan, test, train, threshold, all_zero, all_one, ls
     return dict(decision=v2[decision], count=v2[count], sorted_dists=np.stack([v2[w] for w in sdists]), dists=gathered[:, ncol])
 
 
+def knn_decisions_batched(ck, plan, tests, train, threshold, all_zero, all_one, lsb_one, zero, rank=0, world=1, all_reduce=None, stats=None):
+    """The reference's loop over test records (`for i < test_row_size`, src/KNN_medical_data.cpp:676-691) as ONE batched evaluation:
+    every test record is an instance of the same two DAGs (KnnPlan.phase1 over all train rows, KnnPlan.phase2) and the instances walk
+    the levels side by side (dag_run_batch), so that the 879 levels of the sort / vote chain that hold 1-3 gates per decision hold
+    Q-3Q gates per launch.  Sharding is BY QUERY: rank r evaluates the test records q with q % world == r, both phases, with no
+    exchange in between; one all_reduce at the end gathers the results (every record is produced by exactly one rank, so the sum is
+    the gather).  Gates are deterministic, so record q's result equals knn_decision_sharded on tests[q] bit for bit.
+    tests: int32[Q][ncol][nb][words]; the other arguments as in knn_decision_sharded.
+    Returns dict(decision=[Q][words], count=[Q][nb][words], sorted_dists=[Q][ntrain][nb][words], dists=[Q][ntrain][nb][words])."""
+    nb, ncol, ntrain = plan.nb, plan.ncol, plan.ntrain
+    words = ck.words
+    tests = np.asarray(tests, np.int32)
+    tests = tests.reshape(-1, ncol, nb, words)
+    Q = tests.shape[0]
+    train = np.asarray(train, np.int32).reshape(ntrain, ncol, nb, words)
+    consts = [np.asarray(v, np.int32).reshape(nb, words) for v in (all_zero, all_one, lsb_one)]
+    zero = np.asarray(zero, np.int32).reshape(1, words)
+    thr = np.asarray(threshold, np.int32).reshape(nb, words)
+    mine = [q for q in range(Q) if q % world == rank]
+    per = 1 + nb + 2 * ntrain * nb                       # decision | count | sorted distances | distances
+    result = np.zeros((Q, per, words), np.int32)
+    st1, st2 = {}, {}
+    if mine:
+        c1, dist, copies = plan.phase1(ntrain)
+        shared = np.concatenate([train.reshape(-1, words)] + consts + [zero])
+        in1 = np.stack([np.concatenate([tests[q].reshape(-1, words), shared]) for q in mine])
+        sel1 = [w for r in range(ntrain) for col in range(ncol) for w in copies[r][col]] + [w for r in range(ntrain) for w in dist[r]]
+        _t = time.perf_counter()
+        o1 = evaluate_batch(ck, c1, in1, sel1, st1)
+        st1["seconds"] = time.perf_counter() - _t
+        del in1
+        c2, decision, count, sdists, _ = plan.phase2()
+        tail = np.concatenate([thr] + consts + [zero])
+        in2 = np.concatenate([o1, np.broadcast_to(tail, (len(mine),) + tail.shape)], axis=1)   # rows, dists | thr, constants, zero
+        sel2 = [decision] + list(count) + [w for d in sdists for w in d]
+        _t = time.perf_counter()
+        o2 = evaluate_batch(ck, c2, in2, sel2, st2)
+        st2["seconds"] = time.perf_counter() - _t
+        result[mine, :1 + nb + ntrain * nb] = o2
+        result[mine, 1 + nb + ntrain * nb:] = o1[:, ntrain * ncol * nb:]
+    if world > 1:
+        if all_reduce is None:
+            raise ValueError("knn_decisions_batched: world > 1 needs an all_reduce callable")
+        result = np.asarray(all_reduce(result), np.int32).reshape(result.shape)
+    if stats is not None:
+        stats.update(phase1=st1, phase2=st2, my_queries=mine)
+    a, b = 1 + nb, 1 + nb + ntrain * nb
+    return dict(decision=result[:, 0], count=result[:, 1:a], sorted_dists=result[:, a:b].reshape(Q, ntrain, nb, words),
+                dists=result[:, b:].reshape(Q, ntrain, nb, words))
+
+
 def torch_all_reduce(device=None):
     """all_reduce callable for knn_decision_sharded over torch.distributed (backend nccl = RCCL: pass the rank's cuda device)."""
     import torch
@@ -347,14 +398,16 @@ simulate_ext = simulate
 
 
 def simulate_mk(cir, input_bits):
-    """simulate() plus the 3-gen three-input AND (3gen_mk_gates.jl:55-64)."""
+    """simulate() plus the 3-gen three-input AND exactly as the reference defines it (3gen_mk_gates.jl:55-64): bootstrap of
+    -1/4 + x + y + z.  Three false operands give the phase -5/8 = +3/8 (mod 1), so the reference's gate answers TRUE there -- it is a
+    correct AND only when at least one operand is true.  The simulation mirrors the gate, not the name."""
     from . import AND3
     v = np.zeros(cir.n_wires(), bool)
     v[:cir.n_inputs] = np.asarray(input_bits, bool)
     for gi, (op, a, b, c) in enumerate(cir.gates):
         o = cir.n_inputs + gi
         if op == AND3:
-            v[o] = v[a] and v[b] and v[c]
+            v[o] = (v[a] and v[b] and v[c]) or not (v[a] or v[b] or v[c])
         else:
             one = Circuit()
             one.n_inputs = o
@@ -374,6 +427,47 @@ def evaluate(ck, cir, input_records, stats=None):
             stats.update(cir.census(), **st)
         return vals
     return evaluate_levels(ck, cir, input_records, stats)
+
+
+def evaluate_batch(ck, cir, input_records, out_wires=None, stats=None):
+    """`instances` evaluations of one DAG side by side.  input_records: int32[instances][n_inputs][words]; out_wires: wire ids to return
+    (None: every wire).  Returns int32[instances][len(out_wires) or n_wires][words].  Contexts with the native executor use
+    thfhe_dag_run_batch / thfhe_mk_dag_run_batch (wire tables stay in HBM); others are driven level by level from the host, a level's
+    call holding the gates of all instances."""
+    x = np.ascontiguousarray(input_records, np.int32)
+    Q, n_in, words = x.shape
+    assert n_in == cir.n_inputs
+    if hasattr(ck, "dag_run_batch"):
+        sel = None if out_wires is None else np.asarray(out_wires, np.int32)
+        out, st = ck.dag_run_batch(x, np.array(cir.gates, np.int32).reshape(-1, 4), sel)
+        if stats is not None:
+            stats.update(cir.census(), **st)
+        return out if out_wires is not None else np.concatenate([x, out], axis=1)
+    from . import AND3 as _AND3
+    vals = np.zeros((Q, cir.n_wires(), words), np.int32)
+    vals[:, :n_in] = x
+    gates, base, launches = cir.gates, cir.n_inputs, 0
+    flat = lambda a: a.reshape(-1, words)
+    for level in cir.levels():
+        if gates[level[0]][0] in (NOT, COPY):
+            for g in level:
+                src = vals[:, gates[g][1]]
+                vals[:, base + g] = (0 - src.astype(np.int64)).astype(np.int32) if gates[g][0] == NOT else src
+            continue
+        for cls in ("two", "mux", "and3"):
+            G = [g for g in level if (gates[g][0] == MUX) == (cls == "mux") and (gates[g][0] == _AND3) == (cls == "and3")]
+            if not G:
+                continue
+            a, b = (flat(vals[:, [gates[g][q] for g in G]]) for q in (1, 2))
+            if cls == "two":
+                r = ck.gates_mixed(np.tile(np.array([gates[g][0] for g in G], np.int32), Q), a, b)
+            else:
+                r = ck.gates(MUX if cls == "mux" else _AND3, a, b, flat(vals[:, [gates[g][3] for g in G]]))
+            vals[:, base + np.array(G)] = r.reshape(Q, len(G), words)
+            launches += 1
+    if stats is not None:
+        stats.update(cir.census(), launches=launches, instances=Q)
+    return vals if out_wires is None else vals[:, np.asarray(out_wires, np.int64)]
 
 
 def evaluate_levels(ck, cir, input_records, stats=None):
