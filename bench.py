@@ -88,6 +88,13 @@ def spawn_ranks(n_gpus):
     return rc
 
 
+_gather_objects = lambda obj: [obj]   # replaced by dist_setup when world > 1: list of every rank's object, in rank order
+
+
+def gather_objects(obj):
+    return _gather_objects(obj)
+
+
 def dist_setup(n_gpus):
     """torch.distributed over RCCL ("nccl"); returns (rank, world, barrier, max_reduce, backend).  The world comes from the launcher's
     environment (torch.distributed.run, or spawn_ranks above) and MUST equal --gpus: a mismatch exits non-zero instead of measuring a
@@ -103,6 +110,7 @@ def dist_setup(n_gpus):
         raise SystemExit(2)
     if world == 1:
         return 0, 1, (lambda: None), (lambda x: x), "none"
+    global _gather_objects
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -112,6 +120,10 @@ def dist_setup(n_gpus):
     backend = os.environ.get("THFHE_BENCH_BACKEND", "nccl")
     if backend not in ("nccl", "gloo"):
         raise SystemExit(f"[bench] THFHE_BENCH_BACKEND={backend!r}: expected nccl or gloo")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        # one rank per GPU or nothing: N ranks sharing fewer devices would print an N-GPU line measured on fewer GPUs
+        print(f"[bench] rank {rank}: --gpus {world} over RCCL needs {world} visible GPUs, this node shows {torch.cuda.device_count()}", file=sys.stderr, flush=True)
+        raise SystemExit(4)
     # RCCL / gloo print start-up banners on the C-level stdout: keep stdout clean for the single JSON line
     sys.stdout.flush()
     saved_stdout = os.dup(1)
@@ -146,7 +158,25 @@ def dist_setup(n_gpus):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
+    _gather_objects = gather
     return rank, world, barrier, max_reduce, backend
+
+
+def rank_record(rank, device, gates, seconds):
+    """What one rank contributes to the line's `ranks` list: the device it REALLY ran on (index and PCI bus id from the HIP runtime of the
+    engine's library) and its own rate, so that a multi-GPU record shows N ranks on N different devices."""
+    import ctypes
+    import socket
+    import thfhe
+    buf = ctypes.create_string_buffer(64)
+    ok = thfhe.lib().thfhe_device_pci_bus_id(int(device), buf, 64) == 0
+    return {"rank": rank, "device": int(device), "pci_bus_id": buf.value.decode() if ok else None, "host": socket.gethostname(),
+            "pid": os.getpid(), "gates_per_s": gates / seconds, "seconds": seconds}
 
 
 def cpu_baseline(K, p_name, mk, xa, xb, gpu_out, per_thread):
@@ -291,9 +321,9 @@ def run_party(args, p, rank, world, barrier, max_reduce, backend, device):
     B = args.batch * topo["group_size"]
     # a pipeline of W ranks and C slices runs at C / (C + W - 1) of its steady rate, and a slice should still fill the chip (>= 256 gates:
     # one workgroup per CU); with one rank per group there is no pipeline and the batch goes down in one launch
-    # slices of a group's batch in flight along the party pipeline: 256 gates each (one workgroup per CU) on the ring of degree 1024, 512 on the ring of
-    # degree 2048, where launches above 256 gates run two gates per workgroup (8.5 k against 6.3 k gates/s per GPU)
-    slice_gates = 512 if p.N >= 2048 else 256
+    # slices of a group's batch in flight along the party pipeline: 512 gates each -- launches above 256 gates run two gates per workgroup on both ring
+    # degrees (the pair kernels take the accumulator in and hand it out since round 4)
+    slice_gates = 512
     chunks = args.pipeline_chunks if args.pipeline_chunks > 0 else (1 if topo["group_size"] == 1 else max(1, B // slice_gates))
     ev = PartyShardedEvaluator(p, be, group=group, pipeline_chunks=chunks)
     gseed = 0x5EED0002 + 2 * topo["group"]      # every rank of a group sees the same ciphertexts (mk_internals.jl:23-37)
@@ -311,8 +341,10 @@ def run_party(args, p, rank, world, barrier, max_reduce, backend, device):
     for _ in range(args.steps):
         out = ev.gates(thfhe.NAND, ta, tb)
         torch.cuda.synchronize(be.device)
+    mine = time.perf_counter() - t0
     barrier()
     elapsed = max_reduce(time.perf_counter() - t0)
+    ranks = gather_objects(rank_record(rank, device, B * args.steps / topo["group_size"], mine))   # a rank's share of its group's gates
     rot_ms = [a.elapsed_time(b) for a, b in be.timing]
     got = out.cpu().numpy()
     errors = int((K.decrypt(got) != ~(bits_a.astype(bool) & bits_b.astype(bool))).sum())
@@ -326,9 +358,8 @@ def run_party(args, p, rank, world, barrier, max_reduce, backend, device):
     ab = algorithmic_bytes(p)
     per_rot = jobs_per_launch * (ab["bk"] * (last - first) // p.parties + 2 * 2 * p.N * 8)   # this rank's share of the key stream + accumulator in / out
     avg_ms = float(np.mean(rot_ms)) if rot_ms else None
-    # the piece launches take the accumulator in / out: the one-gate kernels on the ring of degree 1024 (the two-gate kernel there has no hand-over),
-    # the one- or two-gate kernel by launch size on the ring of degree 2048
-    roof = {"kernel": (be.ck.rotation_kernel_name(int(jobs_per_launch)) if p.N >= 2048 else f"mk_blind_rotate_coop_kernel<{p.l}>"),
+    # the piece launches take the accumulator in / out: the one- or two-gate kernel by launch size, on both ring degrees
+    roof = {"kernel": be.ck.rotation_kernel_name(int(jobs_per_launch)),
             "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step, "gates_per_launch": jobs_per_launch,
             "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
             "counters_source": "no PMC pass for the party-sharded piece launches (the kernel is the replicated mode's; see that mode's line)",
@@ -351,6 +382,7 @@ def run_party(args, p, rank, world, barrier, max_reduce, backend, device):
                    "parallelism": f"party pipeline: {topo['groups']} group(s) x {topo['group_size']} rank(s), {last - first} parties per rank, "
                                   f"{chunks} pipeline chunk(s), {'RCCL' if backend == 'nccl' else backend} combine",
                    "mode": "party", "timing_backend": backend},
+        "ranks": ranks, "rccl_world": world if backend == "nccl" else None, "distinct_devices": len({(r["host"], r["pci_bus_id"]) for r in ranks}),
         "roofline": roof, "party_comm": comm, "bit_exact_decrypt_errors": errors,
     }, K, xa, xb, got
 
@@ -433,8 +465,10 @@ def main():
         br_ms.append(tm["blind_rotate_ms"])
         ks_ms.append(tm["keyswitch_ms"])
     ck.sync()
+    mine = time.perf_counter() - t0      # this rank's own clock, before the barrier
     barrier()
     elapsed = max_reduce(time.perf_counter() - t0)
+    ranks = gather_objects(rank_record(rank, device, B * args.steps, mine))
 
     out = do.download((B, words))
     errors = int((K.decrypt(out) != ~(bits_a.astype(bool) & bits_b.astype(bool))).sum())
@@ -489,6 +523,7 @@ def main():
                                f"(P={p.parties}, n={p.n}, N={p.N}, k={p.k}, l={p.l}, Bgbit={p.Bgbit}, ks {p.ks_t}/{p.ks_basebit}), keys+ciphertexts resident in HBM",
                    "gates_per_gpu_per_step": B, "param_set": args.set, "parallelism": f"gate-batch sharding x{world}, replicated keys",
                    "mode": "replicated", "timing_backend": backend},
+        "ranks": ranks, "rccl_world": world if backend == "nccl" else None, "distinct_devices": len({(r["host"], r["pci_bus_id"]) for r in ranks}),
         "roofline": roof,
         "bit_exact_decrypt_errors": errors,
     }

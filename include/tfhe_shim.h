@@ -14,6 +14,7 @@
 #define THFHE_TFHE_SHIM_H
 
 #include <stdint.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -105,6 +106,36 @@ typedef struct TFheGateBootstrappingCloudKeySet {
     const void *bkFFT; /* LweBootstrappingKeyFFT*: never dereferenced */
 } TFheGateBootstrappingCloudKeySet;
 
+/* ---- secret-key side (layouts from the same DWARF: LweKey 16 B, TLweKey 16 B, TGswKey 40 B, SecretKeySet 48 B) ---- */
+typedef struct LweKey {
+    const LweParams *params;
+    int32_t *key;
+} LweKey;
+
+typedef struct IntPolynomial {
+    int32_t N;
+    int32_t *coefs;
+} IntPolynomial;
+
+typedef struct TLweKey {
+    const TLweParams *params;
+    IntPolynomial *key; /* k polynomials */
+} TLweKey;
+
+typedef struct TGswKey {
+    const TGswParams *params;
+    const TLweParams *tlwe_params;
+    IntPolynomial *key; /* = tlwe_key.key */
+    TLweKey tlwe_key;
+} TGswKey;
+
+typedef struct TFheGateBootstrappingSecretKeySet {
+    const TFheGateBootstrappingParameterSet *params;
+    const LweKey *lwe_key;
+    const TGswKey *tgsw_key;
+    TFheGateBootstrappingCloudKeySet cloud;
+} TFheGateBootstrappingSecretKeySet;
+
 void bootsNAND(LweSample *result, const LweSample *ca, const LweSample *cb, const TFheGateBootstrappingCloudKeySet *bk);
 void bootsOR(LweSample *result, const LweSample *ca, const LweSample *cb, const TFheGateBootstrappingCloudKeySet *bk);
 void bootsAND(LweSample *result, const LweSample *ca, const LweSample *cb, const TFheGateBootstrappingCloudKeySet *bk);
@@ -119,6 +150,52 @@ void bootsMUX(LweSample *result, const LweSample *a, const LweSample *b, const L
 void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk);
 void bootsCOPY(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk);
 void bootsCONSTANT(LweSample *result, int32_t value, const TFheGateBootstrappingCloudKeySet *bk);
+
+/* ---- the host half of the libtfhe surface (csrc/tfhe_host.cpp): what the reference's programs call around the gates.
+ * Reference call sites: src/KeyGen.cpp:31-57 (parameters, seed, key generation, key files), src/Convert.cpp:35-70 (bootsSymEncrypt /
+ * bootsSymDecrypt, key files, ciphertext arrays), src/KNN_medical_data.cpp:23-121,163-180 (default parameters, ciphertext files),
+ * src/libthfhe.cpp:316-338 (new_LweParams / new_TLweParams / new_TGswParams), src/bootstrap_modules.cpp:52-55,95 (the seed and bit order of
+ * the committed fixtures).  libtfhe is not in the reference tree; these follow its published behaviour.  Pinned by the reference's fixtures:
+ * the seeded LWE key, the LweSample file record, encoding / decryption.  Key-set files are this library's own containers (unpinned). */
+LweParams *new_LweParams(int32_t n, double alpha_min, double alpha_max);
+TLweParams *new_TLweParams(int32_t N, int32_t k, double alpha_min, double alpha_max);
+TGswParams *new_TGswParams(int32_t l, int32_t Bgbit, const TLweParams *tlwe_params);
+void delete_LweParams(LweParams *p);
+void delete_TLweParams(TLweParams *p);
+void delete_TGswParams(TGswParams *p);
+TFheGateBootstrappingParameterSet *new_default_gate_bootstrapping_parameters(int32_t minimum_lambda);
+void delete_gate_bootstrapping_parameters(TFheGateBootstrappingParameterSet *params);
+void tfhe_random_generator_setSeed(uint32_t *values, int32_t size);
+Torus32 gaussian32(Torus32 message, double sigma);
+Torus32 modSwitchToTorus32(int32_t mu, int32_t Msize);
+int32_t modSwitchFromTorus32(Torus32 phase, int32_t Msize);
+TFheGateBootstrappingSecretKeySet *new_random_gate_bootstrapping_secret_keyset(const TFheGateBootstrappingParameterSet *params);
+void delete_gate_bootstrapping_secret_keyset(TFheGateBootstrappingSecretKeySet *keyset);
+void delete_gate_bootstrapping_cloud_keyset(TFheGateBootstrappingCloudKeySet *keyset);
+LweSample *new_gate_bootstrapping_ciphertext(const TFheGateBootstrappingParameterSet *params);
+LweSample *new_gate_bootstrapping_ciphertext_array(int32_t nbelems, const TFheGateBootstrappingParameterSet *params);
+void delete_gate_bootstrapping_ciphertext(LweSample *sample);
+void delete_gate_bootstrapping_ciphertext_array(int32_t nbelems, LweSample *samples);
+void bootsSymEncrypt(LweSample *result, int32_t message, const TFheGateBootstrappingSecretKeySet *key);
+int32_t bootsSymDecrypt(const LweSample *sample, const TFheGateBootstrappingSecretKeySet *key);
+void export_gate_bootstrapping_ciphertext_toFile(FILE *F, const LweSample *sample, const TFheGateBootstrappingParameterSet *params);
+void import_gate_bootstrapping_ciphertext_fromFile(FILE *F, LweSample *sample, const TFheGateBootstrappingParameterSet *params);
+void export_tfheGateBootstrappingParameterSet_toFile(FILE *F, const TFheGateBootstrappingParameterSet *params);
+TFheGateBootstrappingParameterSet *new_tfheGateBootstrappingParameterSet_fromFile(FILE *F);
+void export_tfheGateBootstrappingCloudKeySet_toFile(FILE *F, const TFheGateBootstrappingCloudKeySet *cloud);
+TFheGateBootstrappingCloudKeySet *new_tfheGateBootstrappingCloudKeySet_fromFile(FILE *F);
+void export_tfheGateBootstrappingSecretKeySet_toFile(FILE *F, const TFheGateBootstrappingSecretKeySet *key);
+TFheGateBootstrappingSecretKeySet *new_tfheGateBootstrappingSecretKeySet_fromFile(FILE *F);
+
+/* torus polynomials of the threshold decryption that follows the gates (ThFHEKeyShare::PartialDecrypt / finalDecrypt, src/libthfhe.cpp:270-314).
+ * torusPolynomialAddMulR[FFT]: result += poly1 (*) poly2 mod X^N + 1, exact, ON THE GPU (N = 1024, |poly1 coefficients| <= 512). */
+TorusPolynomial *new_TorusPolynomial(int32_t N);
+void delete_TorusPolynomial(TorusPolynomial *p);
+void torusPolynomialCopy(TorusPolynomial *result, const TorusPolynomial *sample);
+void torusPolynomialAddTo(TorusPolynomial *result, const TorusPolynomial *poly2);
+void torusPolynomialSubTo(TorusPolynomial *result, const TorusPolynomial *poly2);
+void torusPolynomialAddMulR(TorusPolynomial *result, const IntPolynomial *poly1, const TorusPolynomial *poly2);
+void torusPolynomialAddMulRFFT(TorusPolynomial *result, const IntPolynomial *poly1, const TorusPolynomial *poly2);
 
 /* Batched form for callers that hold arrays of samples (e.g. one adder level): count gates of one kind. */
 int thfhe_tfhe_gate_batch(int op, LweSample *result, const LweSample *ca, const LweSample *cb, const LweSample *cc,

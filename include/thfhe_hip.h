@@ -68,6 +68,9 @@ typedef struct thfhe_ctx thfhe_ctx;
 
 const char *thfhe_last_error(void);
 int thfhe_device_count(void);
+/* PCI bus id ("0000:c1:00.0") of HIP device `device` as this process sees it: bench.py prints it per rank so that a multi-GPU record
+ * shows N ranks on N different devices. */
+int thfhe_device_pci_bus_id(int device, char *buf, int len);
 
 /* Upload + transform the keys to device `device`.  bk_coeff / ksk are HOST pointers, borrowed only
  * for the duration of the call. */

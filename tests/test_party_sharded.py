@@ -146,3 +146,17 @@ def test_party_sharded_n2048_two_gates_per_workgroup(tmp_path):
     outs = run_two_ranks(tmp_path, "hip", dict(n=24, parties=2), gates=5, chunks=1, timeout=900, pset="MK4-N2048", extra_env=dict(THFHE_TEST_PAIR0="1"))
     for o in outs:
         assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt", "replica")), o
+
+
+@pytest.mark.gpu
+def test_party_sharded_n1024_two_gates_per_workgroup(tmp_path):
+    # round 4: mk_blind_rotate_pair_kernel takes the accumulator in and hands it out (acc_in / acc_out of thfhe_mk_rotate_partial_dev), so a
+    # party-sharded slice above 256 gates keeps the two-gates-per-workgroup kernel on the ring of degree 1024.  A 300-gate slice (no forced
+    # threshold: 300 > 256 selects the pair kernel by itself), MK2 shape with a reduced LWE dimension, two ranks with one party each on the one GPU;
+    # then the l = 3 shape (MK4's gadget) on five gates with a lone last gate.
+    outs = run_two_ranks(tmp_path, "hip", dict(n=16), gates=300, chunks=1, timeout=1500)
+    for o in outs:
+        assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt", "replica")), o
+    outs = run_two_ranks(tmp_path, "hip", dict(n=24, parties=2), gates=5, chunks=1, timeout=900, pset="MK4", extra_env=dict(THFHE_TEST_PAIR0="1"))
+    for o in outs:
+        assert all(o[k] for k in ("nand", "xor", "and3", "mux", "not", "bootstrap", "decrypt", "replica")), o

@@ -273,7 +273,14 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
     const int32_t *bara1 = bara0 + (has1 ? a.w_pad : 0);
     const int Bgbit = a.Bgbit;
     const uint64_t offset = decomp_offset64(L, Bgbit);
-    if (wave < 2 && (wave == 0 || has1)) acc_init16_64(lane, sAcc[wave], sAcc[wave] + 1024, a.barb[job0 + wave], a.mu);
+    if (a.acc_in) {   // party-sharded mode: the accumulators of the party block before this one (J/3gen_mk_internals.jl:78-84)
+        for (int q = threadIdx.x; q < 4096; q += 512) {
+            const int g = q >> 11;
+            if (g == 0 || has1) sAcc[g][q & 2047] = a.acc_in[(job0 + g) * 2048 + (q & 2047)];
+        }
+    } else if (wave < 2 && (wave == 0 || has1)) {
+        acc_init16_64(lane, sAcc[wave], sAcc[wave] + 1024, a.barb[job0 + wave], a.mu);
+    }
     __syncthreads();
     const int o = wave >> 2, h = wave & 3;
 
@@ -371,7 +378,14 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
         __syncthreads();  // accumulators updated and scratch free before the next step
         i = inext;
     }
-    if (wave < 2 && (wave == 0 || has1)) extract16_64(lane, sAcc[wave], sAcc[wave] + 1024, a.out + (job0 + wave) * 1025);
+    if (a.acc_out) {
+        for (int q = threadIdx.x; q < 4096; q += 512) {
+            const int g = q >> 11;
+            if (g == 0 || has1) a.acc_out[(job0 + g) * 2048 + (q & 2047)] = sAcc[g][q & 2047];
+        }
+    } else if (wave < 2 && (wave == 0 || has1)) {
+        extract16_64(lane, sAcc[wave], sAcc[wave] + 1024, a.out + (job0 + wave) * 1025);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -974,7 +988,7 @@ int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a) {
         THFHE_HIP(hipGetLastError());
         return THFHE_OK;
     }
-    if (!a.acc_in && !a.acc_out && c->p.l <= 3 && a.jobs > c->pair_threshold) {  // throughput path: two gates per workgroup
+    if (c->p.l <= 3 && a.jobs > c->pair_threshold) {  // throughput path: two gates per workgroup (also for the party-sharded pieces)
         const dim3 pgrid((unsigned)((a.jobs + 1) / 2));
         switch (c->p.l) {
         case 1: hipLaunchKernelGGL(mk_blind_rotate_pair_kernel<1>, pgrid, block, 0, c->stream, a); break;

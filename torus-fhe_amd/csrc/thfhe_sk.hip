@@ -831,6 +831,12 @@ int thfhe_device_count(void) {
     return n;
 }
 
+int thfhe_device_pci_bus_id(int device, char *buf, int len) {
+    if (!buf || len < 16) return thfhe_fail(THFHE_E_INVALID, "buffer of at least 16 bytes expected");
+    THFHE_HIP(hipDeviceGetPCIBusId(buf, len, device));
+    return THFHE_OK;
+}
+
 int thfhe_ctx_create(const thfhe_params *p, const int32_t *bk_coeff, const int32_t *ksk, int device, thfhe_ctx **out) {
     if (!p || !bk_coeff || !ksk || !out) return thfhe_fail(THFHE_E_INVALID, "null argument");
     *out = nullptr;

@@ -140,6 +140,7 @@ _vp = C.c_void_p
 SIGNATURES = {
     "thfhe_last_error": (C.c_char_p, []),
     "thfhe_device_count": (C.c_int, []),
+    "thfhe_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "thfhe_ctx_create": (C.c_int, [C.POINTER(Params), _i32p, _i32p, C.c_int, C.POINTER(_vp)]),
     "thfhe_ctx_destroy": (None, [_vp]),
     "thfhe_ctx_params": (C.c_int, [_vp, C.POINTER(Params)]),
