@@ -95,9 +95,24 @@ __device__ __forceinline__ void wave_fft_inv(int lane, cplx (&z)[8], cplx *xb, c
 __device__ __forceinline__ void ring_dma(const cplx *gptr_lane, uint32_t lds_byte_off) {
     asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "{m0}"(lds_byte_off) : "memory");
 }
+// Hand-off barrier of the ring: this wave's own slice of the chunk has landed (at most VM younger DMAs in flight), every LDS read it issued
+// has returned, then the workgroup barrier.  Two forms: the wait inside an asm (default), or the s_waitcnt BUILTIN -- with the builtin the compiler's
+// wait-count pass knows that nothing is pending on lgkmcnt after the barrier and counts the waits of reads issued right after it exactly (with the asm
+// it puts a conservative lgkmcnt(0) in front of the first multiply after the barrier; harmless in the default order, where no read is pending there).
+// gfx9 encoding of s_waitcnt: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14.
+#ifndef THFHE_RING_ASM_BARRIER
+#define THFHE_RING_ASM_BARRIER 1   // the builtin form times the same (profiles/r04_ring_multiply_phase.md); the asm form is the one every round measured
+#endif
 template <int VM>
 __device__ __forceinline__ void ring_barrier() {
+#if THFHE_RING_ASM_BARRIER
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+#else
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt((VM & 15) | (7 << 4) | (0 << 8) | ((VM >> 4) << 14));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#endif
 }
 __device__ __forceinline__ void wave_fft_fwd_s(int lane, cplx (&z)[8], cplx *xb, const cplx *T1, const W64 &w) {
     wave_sync();

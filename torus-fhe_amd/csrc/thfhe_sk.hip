@@ -153,6 +153,9 @@ struct BRArgs {
 #ifndef THFHE_RING_NF
 #define THFHE_RING_NF 16
 #endif
+#ifndef THFHE_RING_READ_FIRST
+#define THFHE_RING_READ_FIRST 0   // 1 = round 4's experiment (profiles/r04_ring_multiply_phase.md): measured slower, kept for the record
+#endif
 // W = waves (= jobs) per workgroup.  W = 8 is the throughput shape described above.  W = 4 (one wave per SIMD, 92 KiB of LDS, each wave
 // brings TWO slices of a chunk) is the shape for batches that cannot give every CU eight jobs (<= 1024 rotations): a wave alone on its
 // SIMD issues at ~87 % of what a pair reaches together (tools/probes/issue_probe.hip), so four jobs finish much sooner than eight.
@@ -228,11 +231,23 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void sk_blind_rotate_ring_k
             for (int c4 = 0; c4 < 4; c4++) {
                 if (c4 == 0) ring_barrier<2 * DPC>(); else ring_barrier<DPC>();
                 STAMP(1);
-                if (c4 > 0) issue();
                 const cplx *B = &sRing[slot_use][0];
+#if THFHE_RING_READ_FIRST
+                // the chunk's first four reads go out the moment the barrier falls (the eight waves' reads of a chunk keep the LDS array busy for
+                // 256 cycles: they, not the arithmetic, are the longest thing between two barriers), then the refill DMA, then the arithmetic
                 if (active) {
 #pragma unroll
                     for (int m = 0; m < 4; m++) bA[m] = B[m * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (c4 > 0) issue();
+                if (active) {
+#else
+                if (c4 > 0) issue();
+                if (active) {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) bA[m] = B[m * 64 + lane];
+#endif
                     if (c4 > 0) {
 #pragma unroll
                         for (int m = 0; m < 4; m++) cfma(S[(c4 - 1) >> 1][(c4 - 1) & 1][4 + m], z[4 + m], bB[m]);
