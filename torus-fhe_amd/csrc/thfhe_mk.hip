@@ -935,7 +935,15 @@ int mk_launch_rotation(thfhe_mk_ctx *c, const MKBRArgs &a) {
         if (!a.acc_in) hipLaunchKernelGGL(mk_acc_init_2k_kernel, dim3((unsigned)a.jobs), dim3(256), 0, c->stream, a.barb, a.mu, a.jobs, acc, 4096);
         else if (a.acc_in != acc) THFHE_HIP(hipMemcpyAsync(acc, a.acc_in, (size_t)a.jobs * 8192 * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
         R4KArgs k{c->d_bk, c->d_tw, a.bara, acc, a.jobs, a.pn, c->p.l, c->p.Bgbit, c->parts, c->pw, a.w_pad};
-        hipLaunchKernelGGL(r4k_rotate_kernel, grid, block, 0, c->stream, k);
+        if ((size_t)a.jobs > c->park.cap_wgs) {   // 128 KiB per workgroup for the parked partial spectra (thfhe_rot4k.h)
+            THFHE_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->park.buf);
+            c->park.buf = nullptr;
+            c->park.cap_wgs = 0;
+            THFHE_HIP(hipMalloc(&c->park.buf, (size_t)a.jobs * 8 * 2 * 512 * sizeof(cplx)));
+            c->park.cap_wgs = (size_t)a.jobs;
+        }
+        hipLaunchKernelGGL(r4k_rotate_kernel, grid, block, 0, c->stream, k, c->park.buf);
         if (!a.acc_out) hipLaunchKernelGGL(mk_extract_kernel, grid, dim3(256), 0, c->stream, (const int64_t *)acc, a.out, a.jobs, 4096);
         THFHE_HIP(hipGetLastError());
         return THFHE_OK;

@@ -7,6 +7,12 @@
 // inverse transforms, the radix-4 merge and the integer atomics.  These sets run 46 k - 374 k sequential CMuxes per gate: the kernel is
 // written for exactness and for fitting the CU, not tuned.  Included inside thfhe_mk.hip's anonymous namespace after thfhe_rot2k.h.
 #pragma once
+// nothing is scheduled across this point: without it the multiply-accumulates of a row sink below the requests for the next row's key chunk and the
+// registers of both rows, the spectrum points and the partial sums are live at once
+#define R4K_FENCE() do { kms_pin(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef R4K_EARLY_KEY
+#define R4K_EARLY_KEY 0
+#endif
 
 // torus polynomials int64[npolys][4096] -> limb spectra [poly][limb h][quarter][512], scaled by 1/2048 (one wave per (poly, limb))
 __global__ __launch_bounds__(256) void r4k_key_transform_kernel(const int64_t *__restrict__ polys, long npolys, const cplx *__restrict__ tw,
@@ -76,7 +82,10 @@ __device__ __forceinline__ void r4k_group_digits(const uint64_t *src, int c, int
         u[s] = cplx{d[0], d[1]};
     }
 }
-__global__ __launch_bounds__(512, 2) void r4k_rotate_kernel(R4KArgs a) {
+// Register budget: a wave's four partial quarter spectra are 128 VGPRs; next to the digit work of a pass (two tasks of 32 VGPRs + key rows) they
+// spilled 1 108 B per lane.  So a pass keeps only ITS two partial spectra (64 VGPRs): pass 0 parks them in global memory (`park`, 16 KiB per wave:
+// cplx[workgroup][wave][2][512], coalesced 16-B accesses, L2-resident) and the inverse phase takes them back after pass 1's two are transformed.
+__global__ __launch_bounds__(512, 2) void r4k_rotate_kernel(R4KArgs a, cplx *__restrict__ park) {
     constexpr int ROWP = 6;   // row parts (2 l parts): the reference's sets have exactly six; fewer are allowed
     constexpr int PRE = 2;
     __shared__ int64_t sAcc[2 * 4096];
@@ -86,6 +95,7 @@ __global__ __launch_bounds__(512, 2) void r4k_rotate_kernel(R4KArgs a) {
     const long job = blockIdx.x;
     const int32_t *bara = a.bara + job * a.bara_stride;
     int64_t *gacc = a.acc + job * 8192;
+    cplx *mypark = park + (((size_t)blockIdx.x * 8 + wave) * 2) * 512;
     const int RP = 2 * a.l * a.parts;
     const uint64_t offset = decomp_offset64(a.l, a.Bgbit);
     for (int q = threadIdx.x; q < 8192; q += 512) sAcc[q] = gacc[q];
@@ -103,12 +113,8 @@ __global__ __launch_bounds__(512, 2) void r4k_rotate_kernel(R4KArgs a) {
         const int ai = bara[i];
         if (ai == 0) continue;   // uniform
         const int a2n = ai & 8191;
-        cplx S[4][8];
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int m = 0; m < 8; m++) S[t][m] = cplx{0.0, 0.0};
-        auto pass = [&](auto pass_index) {   // quarters 2P and 2P + 1; P is a compile-time constant (partial spectra stay in registers)
+        cplx S[2][8];   // the partial spectra of the pass at hand (quarters 2P, 2P + 1)
+        auto pass = [&](auto pass_index) {   // quarters 2P and 2P + 1; P is a compile-time constant
             constexpr int P = decltype(pass_index)::value;
             // ---- rotated words of both accumulator polynomials: 16 coefficients per lane
             {
@@ -143,10 +149,12 @@ __global__ __launch_bounds__(512, 2) void r4k_rotate_kernel(R4KArgs a) {
             // ---- forward quarter transforms into the slots; first key chunks requested
             cplx B[PRE][8];
             const int gl = opaque_lane(lane);
+#if R4K_EARLY_KEY
             kms_pin();
             load8(gl, B[0], chunk(i, 0, 2 * P));
             load8(gl, B[1], chunk(i, 0, 2 * P + 1));
             kms_pin();
+#endif
             {
                 const int ln = opaque_lane(lane);
                 const W64 w64{a.tw[1024 + 1 * 8 + (ln & 7)]};
@@ -165,24 +173,47 @@ __global__ __launch_bounds__(512, 2) void r4k_rotate_kernel(R4KArgs a) {
                 if (t0) transform(q0, q0 * ROWP + rp0, y0);
                 if (t1) transform(q1, q1 * ROWP + rp1, y1);
             }
+#if R4K_EARLY_KEY
             lds_barrier<8 * PRE>();   // spectra published
+#else
+            // the first key rows are requested AFTER the transforms: held across them (64 VGPRs next to two tasks' points and twiddles) they were
+            // spilled as soon as they arrived
+            kms_pin();
+            load8(gl, B[0], chunk(i, 0, 2 * P));
+            load8(gl, B[1], chunk(i, 0, 2 * P + 1));
+            kms_pin();
+            lds_barrier<8 * PRE>();   // spectra published
+#endif
             // ---- multiply: row part q, quarters 2P (chunk in B[0]) and 2P + 1 (B[1])
 #pragma unroll
-            for (int q = 0; q < ROWP; q++) {
-                if (q < RP) {
-                    r2k_mac_slot<1>(S[2 * P], sSpec + q * 512, lane, B[0]);
-                    kms_pin();
-                    if (q + 1 < RP) load8(gl, B[0], chunk(i, q + 1, 2 * P));
-                    kms_pin();
-                    r2k_mac_slot<1>(S[2 * P + 1], sSpec + (ROWP + q) * 512, lane, B[1]);
-                    kms_pin();
-                    if (q + 1 < RP) load8(gl, B[1], chunk(i, q + 1, 2 * P + 1));
-                    kms_pin();
-                }
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int m = 0; m < 8; m++) S[t][m] = cplx{0.0, 0.0};
+            // a ROLLED loop over the row parts: unrolled (six conditional bodies, each with its requests for the next row) the allocator kept the
+            // rows of several bodies live at once and spilled 900 B per lane; the unconditional request of the last body re-reads its own row
+#pragma unroll 1
+            for (int q = 0; q < RP; q++) {
+                const int qn = q + 1 < RP ? q + 1 : q;
+                r2k_mac_slot<1>(S[0], sSpec + q * 512, lane, B[0]);
+                R4K_FENCE();
+                load8(gl, B[0], chunk(i, qn, 2 * P));
+                R4K_FENCE();
+                r2k_mac_slot<1>(S[1], sSpec + (ROWP + q) * 512, lane, B[1]);
+                R4K_FENCE();
+                load8(gl, B[1], chunk(i, qn, 2 * P + 1));
+                R4K_FENCE();
             }
             lds_barrier<0>();   // spectra consumed
         };
         pass(std::integral_constant<int, 0>{});
+        {   // quarters 0 / 1 leave the registers for the length of pass 1
+            const int gl = opaque_lane(lane);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                mypark[m * 64 + gl] = S[0][m];
+                mypark[512 + m * 64 + gl] = S[1][m];
+            }
+        }
         pass(std::integral_constant<int, 1>{});
         // ---- four inverse quarter transforms, radix-4 merge, round(S) << 16h into accumulator polynomial o
         {
@@ -190,14 +221,19 @@ __global__ __launch_bounds__(512, 2) void r4k_rotate_kernel(R4KArgs a) {
             const int ln = opaque_lane(lane);
             const W64 w64{a.tw[1024 + 1 * 8 + (ln & 7)]};
             const cplx ratio = a.tw[1216 + ln];
-            wave_fft_inv_tq<1, 64>(ln, S[0], xb, LaneRoots{a.tw[1280 + ln], ratio}, w64);
-            wave_fft_inv_tq<5, 64>(ln, S[1], xb, LaneRoots{a.tw[1280 + 64 + ln], ratio}, w64);
-            wave_fft_inv_tq<9, 64>(ln, S[2], xb, LaneRoots{a.tw[1280 + 128 + ln], ratio}, w64);
-            wave_fft_inv_tq<13, 64>(ln, S[3], xb, LaneRoots{a.tw[1280 + 192 + ln], ratio}, w64);
+            cplx Sa[8], Sb[8];
+            kms_pin();
+            load8(ln, Sa, mypark);         // requested ahead of the two transforms that do not need them
+            load8(ln, Sb, mypark + 512);
+            kms_pin();
+            wave_fft_inv_tq<9, 64>(ln, S[0], xb, LaneRoots{a.tw[1280 + 128 + ln], ratio}, w64);
+            wave_fft_inv_tq<13, 64>(ln, S[1], xb, LaneRoots{a.tw[1280 + 192 + ln], ratio}, w64);
+            wave_fft_inv_tq<1, 64>(ln, Sa, xb, LaneRoots{a.tw[1280 + ln], ratio}, w64);
+            wave_fft_inv_tq<5, 64>(ln, Sb, xb, LaneRoots{a.tw[1280 + 64 + ln], ratio}, w64);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 cplx z[4];
-                merge4096(S[0][m], S[1][m], S[2][m], S[3][m], z);
+                merge4096(Sa[m], Sb[m], S[0][m], S[1][m], z);
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int c = lane + 64 * m + 512 * s;

@@ -178,6 +178,25 @@ function dag_run(ck::HipCloudKey, inputs::Matrix{Int32}, gates::Matrix{Int32})
     wires
 end
 
+"""
+    dag_run_batch(ck, inputs, gates[, out_wires]) -> outputs
+
+The reference's loop over test records around one circuit (`for i < test_row_size`, src/KNN_medical_data.cpp:676-691) as ONE evaluation:
+`inputs :: Array{Int32,3}` (n+1, n_inputs, instances); every instance walks the levels of `gates` side by side (a level's launch holds
+instances x its gates).  `out_wires` (0-based wire ids) selects the wires to return; default: every gate wire.  Returns
+(n+1, length(out_wires) or n_gates, instances).
+"""
+function dag_run_batch(ck::HipCloudKey, inputs::Array{Int32,3}, gates::Matrix{Int32}, out_wires::Union{Nothing, Vector{Int32}}=nothing)
+    ni, q, ng = size(inputs, 2), size(inputs, 3), size(gates, 2)
+    nout = out_wires === nothing ? ng : length(out_wires)
+    out = zeros(Int32, size(inputs, 1), nout, q)
+    sel = out_wires === nothing ? Ptr{Int32}(C_NULL) : pointer(out_wires)
+    GC.@preserve out_wires check(ccall((:thfhe_dag_run_batch, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Int32}, Csize_t, Ptr{Int32}, Csize_t, Csize_t, Ptr{Int32}, Csize_t, Ptr{Int32}, Ptr{Int64}),
+        ck.h, inputs, ni, gates, ng, q, sel, out_wires === nothing ? 0 : nout, out, C_NULL))
+    out
+end
+
 # ---- after the gate path: TLweFromLwe / PartialDecrypt / finalDecrypt (src/libthfhe.cpp:270-348) ---------------------------
 mutable struct HipPolyContext
     h::Ptr{Cvoid}
