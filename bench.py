@@ -272,7 +272,7 @@ def load_counters(param_set, batch, kernel):
 
 def make_keys(args, p, mk, device):
     """Synthetic key material of SURVEY.md section 8(d): deterministic seed, the parameter set's own noise levels (thfhe.SIGMAS, KeyError
-    for a set without an entry).  The 16+-party sets generate their bootstrapping key on the device (section 13 of DESIGN.md)."""
+    for a set without an entry).  The 16+-party sets generate their bootstrapping key on the device."""
     import thfhe
     from thfhe import keygen
     sig = thfhe.SIGMAS[args.set]
@@ -411,7 +411,7 @@ def main():
         return dry_topology(args)
 
     if args.mode == "party":
-        os.environ["THFHE_TORCH_FIRST"] = "1"   # torch before libthfhe_hip.so (DESIGN.md section 7): the piece API works on torch tensors
+        os.environ["THFHE_TORCH_FIRST"] = "1"   # torch before libthfhe_hip.so (DESIGN.md section 6): the piece API works on torch tensors
     import thfhe
 
     rank, world, barrier, max_reduce, backend = dist_setup(args.gpus)

@@ -123,7 +123,7 @@ def test_new_entry_points_validate_arguments_without_a_device():
 
 
 def test_multi_rank_processes_load_torch_before_the_engine():
-    """Runtime-order rule (DESIGN.md section 7): torch bundles its own HIP runtime, and loading libthfhe_hip.so first hides the GPU
+    """Runtime-order rule (DESIGN.md section 6): torch bundles its own HIP runtime, and loading libthfhe_hip.so first hides the GPU
     from torch.  thfhe.lib() therefore imports torch itself in a multi-rank job (WORLD_SIZE > 1) -- and does not in a single process."""
     import subprocess
     import sys

@@ -50,7 +50,7 @@ def test_forward_transform_matches_definition(E):
 
 @pytest.mark.parametrize("case", ["random7", "random10", "worst_neg", "worst_alt"])
 def test_polymul_exact_with_margin(E, O, case):
-    # exactness claim of DESIGN.md section 4: every inverse-transform output is within << 1/2 of an integer
+    # exactness claim of DESIGN.md section 3: every inverse-transform output is within << 1/2 of an integer
     N = 1024
     rng = np.random.default_rng(1)
     if case == "random7":
