@@ -1,6 +1,7 @@
 """Round 4: the parameter sets that earlier rounds only extrapolated or checked at reduced size, run at the reference's FULL size on one MI355X
 and compared with the CPU oracle where the oracle affords it (verdict r03, "Run what was only extrapolated, and check it").  One JSON line per
-check; `python tools/full_size_checks.py <check> [...]`, checks:
+check; `python tests/full_size_checks.py <check> [...]` (a script, not collected by pytest: minutes of GPU + host time per check; it lives under
+tests/ because it calls the CPU oracle, which is test infrastructure), checks:
 
   mk32      mktfhe_parameters_32party_3gen (mk_api.jl:225-231 region): P = 32, n = 620, N = 2048 -- a batch timed + decrypted, 2 gates word for word vs the oracle
   mk64 / mk128   the 64- and 128-party sets the same way (1 oracle gate each: 42 k / 86 k sequential CMuxes on one host thread)
@@ -8,6 +9,7 @@ check; `python tools/full_size_checks.py <check> [...]`, checks:
             HBM, one batch timed + decrypted, 1 gate vs the oracle at the full size (189 k CMuxes)
   kms2      mktfhe_parameters_2party_new (mk_api.jl:12-20) at n = 560: 8 gates (and 8 fast_boot gates) word for word vs the oracle, OpenMP over gates
   mk64fft / mk512   the sets on the ring of degree 4096 (mk_api.jl:277-283, 316-322): timing + decryption at full size (mk512: as many parties as fit)
+  mk64fft-oracle   the 64-party set on the ring of degree 4096 with a VALID key set (from the oracle's key generation): 64 gates decrypted, 1 gate vs the oracle
   ccs16     the 16-party CCS set (mk_api.jl:185-191), n = 560: timing + decryption at full size
 Keys of the 3-gen sets are generated on the device (thfhe_pm_mac under thfhe/keygen.py) from the host's randomness, so the oracle sees the same key."""
 import json
@@ -19,7 +21,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "torus-fhe_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # oracle_lib
 import thfhe
 from thfhe import keygen
 
@@ -125,6 +127,47 @@ def ccs16_check(batch=64):
     ck.close()
 
 
+def mk_oracle_keys_check(name, batch, oracle_gates):
+    """A set whose keys the device key generation cannot make (ring of degree 4096): key material from the ORACLE's key generation (single-threaded C,
+    minutes at full size), the batch on the GPU, every output decrypted, `oracle_gates` gates word for word against the oracle."""
+    import threading
+    import oracle_lib as O
+    p = O.make_params(name)
+    s = O.SIGMAS[name]
+    stop = threading.Event()
+    threading.Thread(target=lambda: [note(f"{name}: oracle key generation still running") for _ in iter(lambda: stop.wait(120), True)], daemon=True).start()
+    t0 = time.time()
+    K = O.MKKeys(p, 0x5EED0001, s["bk"], s["ks"])
+    t_key = time.time() - t0
+    stop.set()
+    note(f"{name}: keys generated by the oracle in {t_key:.0f} s ({K.bk.nbytes / 1e9:.1f} GB + {K.ksk.nbytes / 1e9:.1f} GB)")
+    t0 = time.time()
+    ck = thfhe.MKCloudKey(thfhe.make_params(name), K.bk, K.ksk, device=0)
+    t_ctx = time.time() - t0
+    rng = np.random.default_rng(0)
+    a, b = rng.integers(0, 2, batch), rng.integers(0, 2, batch)
+    xa, xb = K.encrypt_bits(a, s["lwe"], 1), K.encrypt_bits(b, s["lwe"], 2)
+    ck.gates(thfhe.NAND, xa[:2], xb[:2])
+    t0 = time.time()
+    out = ck.gates(thfhe.NAND, xa, xb)
+    dt = time.time() - t0
+    note(f"{name}: {batch} gates in {dt:.2f} s")
+    ok = bool(np.array_equal(K.decrypt_bits(out), ~(a.astype(bool) & b.astype(bool))))
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    O.lib().oracle_set_threads(min(oracle_gates, O.usable_cpus()))
+    stop = threading.Event()
+    threading.Thread(target=lambda: [note(f"{name}: oracle gate(s) still running") for _ in iter(lambda: stop.wait(120), True)], daemon=True).start()
+    t0 = time.time()
+    ref = orc.gates(O.NAND, xa[:oracle_gates], xb[:oracle_gates])
+    t_or = time.time() - t0
+    stop.set()
+    emit(check=name, workload=f"{batch} mk_gate_nand_3gen, {name} at full size (P={p.parties}, n={p.n}, N={p.N}, l={p.l}, Bgbit={p.Bgbit}, ks {p.ks_t}/{p.ks_basebit}), keys from the oracle's key generation",
+         kernel=ck.rotation_kernel_name(batch), cmuxes_per_gate=p.parties * p.n, key_coefficients_gb=K.bk.nbytes / 1e9, gates_per_s=batch / dt, seconds=dt,
+         oracle_keygen_s=t_key, ctx_create_s=t_ctx, all_decrypt_correct=ok, oracle_gates=oracle_gates, oracle_seconds=t_or,
+         words_equal_to_oracle=bool(np.array_equal(out[:oracle_gates], ref)), words_compared=int(ref.size))
+    ck.close()
+
+
 def mk_timing_synthetic(name, batch, parties=None):
     """Timing of a set whose key generation is not available at full size in this tree (the device key-generation products stop at N = 2048 and
     the host path needs hours at N = 4096): key tables of the right SHAPE filled with random words / zeros.  Kernel time does not depend on key
@@ -163,6 +206,7 @@ CHECKS = {
     "mk64fft": lambda: mk_timing_synthetic("MK64-fft", 256),
     "mk512": lambda: mk_timing_synthetic("MK512", 256, parties=int(os.environ.get("MK512_PARTIES", "128"))),
     "ccs16": ccs16_check,
+    "mk64fft-oracle": lambda: mk_oracle_keys_check("MK64-fft", 64, 1),
 }
 
 if __name__ == "__main__":
