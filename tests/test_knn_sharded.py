@@ -9,6 +9,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -38,6 +39,10 @@ SCRIPT = """
                 out[m] = self.orc.gates(int(op), x[m], y[m])
             return out
 
+    if os.environ.get("KNN_ENGINE") == "hip":   # the product engine on the box's GPU (both ranks share device 0): native thfhe_dag_run[_batch]
+        import thfhe
+        ck = thfhe.CloudKey(thfhe.make_params(**p.as_dict()), K.bk, K.ksk, device=0)
+        OracleKey = lambda: ck
     nb, ncol, ntrain = 6, 4, 3
     test = [0, 17, 40, 1]
     train = [[1, 20, 35, 1], [2, 3, 44, 0], [3, 16, 41, 1]]
@@ -121,3 +126,17 @@ def test_knn_queries_dealt_over_two_gloo_ranks(tmp_path):
     assert sorted(sum((o["queries"] for o in two), [])) == [0, 1, 2] and [o["queries"] for o in sorted(two, key=lambda o: o["rank"])] == [[0, 2], [1]]
     for o in two:
         assert o["sha"] == one["sha"], "by-query sharding differs from the single-rank batch"
+
+
+@pytest.mark.gpu
+def test_knn_queries_two_ranks_on_one_gpu_equal_the_oracle_engine(tmp_path):
+    """The same by-query split with the PRODUCT engine: two gloo ranks share the box's MI355X, each evaluates its test records through
+    thfhe_dag_run_batch; the gathered ciphertexts must equal, bit for bit, what ONE rank computes with the CPU oracle as engine (GPU == oracle),
+    and the single-decision path on the GPU must equal instance 0."""
+    oracle_one = run(tmp_path, 1, KNN_QUERIES="1")[0]
+    hip_two = run(tmp_path, 2, KNN_QUERIES="1", KNN_ENGINE="hip")
+    hip_single_decision = run(tmp_path, 1, KNN_ENGINE="hip")[0]
+    assert hip_single_decision["sha"] == oracle_one["sha"][0]
+    for o in hip_two:
+        assert o["sha"] == oracle_one["sha"], "GPU by-query evaluation differs from the oracle-engine batch"
+        assert o["decision"] == [True, True, True] and o["count"] == [2, 2, 2]
