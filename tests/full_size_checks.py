@@ -10,6 +10,8 @@ tests/ because it calls the CPU oracle, which is test infrastructure), checks:
   kms2      mktfhe_parameters_2party_new (mk_api.jl:12-20) at n = 560: 8 gates (and 8 fast_boot gates) word for word vs the oracle, OpenMP over gates
   mk64fft / mk512   the sets on the ring of degree 4096 (mk_api.jl:277-283, 316-322): timing + decryption at full size (mk512: as many parties as fit)
   mk64fft-oracle   the 64-party set on the ring of degree 4096 with a VALID key set (from the oracle's key generation): 64 gates decrypted, 1 gate vs the oracle
+  ccs{2,4,8,16}-oracle   the CCS sets (mk_api.jl:4-10, 56-62, 111-117, 185-191) at n = 560 with the oracle's keys: 8 / 4 / 2 / 1 gates vs the oracle
+  kms4 / kms8   the 4- and 8-party KMS sets (mk_api.jl:64-72, 120-128) at n = 560: 2 / 1 gates vs the oracle
   ccs16     the 16-party CCS set (mk_api.jl:185-191), n = 560: timing + decryption at full size
 Keys of the 3-gen sets are generated on the device (thfhe_pm_mac under thfhe/keygen.py) from the host's randomness, so the oracle sees the same key."""
 import json
@@ -106,6 +108,74 @@ def kms2_check(gates=8, batch=256):
          fast_boot_all_decrypt_correct=bool(np.array_equal(K.decrypt(outf), want)), oracle_gates=gates, oracle_seconds=t_or,
          words_equal_to_oracle=bool(np.array_equal(out[:gates], ref)), fast_boot_words_equal_to_oracle=bool(np.array_equal(outf[:gates], reff)),
          words_compared=int(ref.size) * 2)
+    ck.close()
+
+
+def ccs_oracle_check(name, batch, oracle_gates):
+    """A CCS set (mk_gate_nand, J/mk_gates.jl:7-13) at its full size, key material from the oracle's key generation: the batch on the GPU, every
+    output decrypted, `oracle_gates` gates word for word against the oracle."""
+    import threading
+    import oracle_lib as O
+    p = O.make_params(name)
+    s = O.SIGMAS[name]
+    t0 = time.time()
+    K = O.CCSKeys(p, 0x5EED0001, s["bk"], s["ks"])
+    t_key = time.time() - t0
+    note(f"{name}: keys from the oracle in {t_key:.0f} s")
+    ck = thfhe.CCSCloudKey(thfhe.make_params(**p.as_dict()), K.bk, K.pk, K.crs, K.ksk, device=0)
+    rng = np.random.default_rng(0)
+    a, b = rng.integers(0, 2, batch), rng.integers(0, 2, batch)
+    xa, xb = K.encrypt_bits(a, s["lwe"], 1), K.encrypt_bits(b, s["lwe"], 2)
+    thfhe.mk_gate_nand(ck, xa[:2], xb[:2])
+    t0 = time.time()
+    out = thfhe.mk_gate_nand(ck, xa, xb)
+    dt = time.time() - t0
+    note(f"{name}: {batch} gates in {dt:.2f} s")
+    orc = O.CCSOracle(p, K)
+    O.lib().oracle_set_threads(min(oracle_gates, O.usable_cpus()))
+    stop = threading.Event()
+    threading.Thread(target=lambda: [note(f"{name}: oracle gate(s) still running") for _ in iter(lambda: stop.wait(120), True)], daemon=True).start()
+    t0 = time.time()
+    ref = orc.gates(O.NAND, xa[:oracle_gates], xb[:oracle_gates])
+    t_or = time.time() - t0
+    stop.set()
+    emit(check=name, workload=f"{batch} mk_gate_nand (CCS), {name} at full size (P={p.parties}, n={p.n}, N={p.N}, l={p.l}, Bgbit={p.Bgbit}), keys from the oracle's key generation",
+         gates_per_s=batch / dt, seconds=dt, oracle_keygen_s=t_key, all_decrypt_correct=bool(np.array_equal(K.decrypt_bits(out), ~(a.astype(bool) & b.astype(bool)))),
+         oracle_gates=oracle_gates, oracle_seconds=t_or, words_equal_to_oracle=bool(np.array_equal(out[:oracle_gates], ref)), words_compared=int(ref.size))
+    ck.close()
+
+
+def kms_check(name, batch, oracle_gates):
+    """A KMS set (mk_gate_nand_new) at its full size: batch on the GPU, decrypted; `oracle_gates` gates word for word against the oracle."""
+    import threading
+    import oracle_lib as O
+    from thfhe import kms
+    p = thfhe.make_kms_params(name)
+    t0 = time.time()
+    K = keygen.KMSSecretKeySet(p, seed=1)
+    t_key = time.time() - t0
+    note(f"{name}: host key generation {t_key:.0f} s")
+    ck = kms.KMSCloudKey(p, K.gsw, K.uni, K.pk, K.crs, K.ksk, device=0)
+    rng = np.random.default_rng(0)
+    a, b = rng.integers(0, 2, batch), rng.integers(0, 2, batch)
+    xa, xb = K.encrypt(a, 1), K.encrypt(b, 2)
+    kms.mk_gate_nand_new(ck, xa[:2], xb[:2])
+    t0 = time.time()
+    out = kms.mk_gate_nand_new(ck, xa, xb)
+    dt = time.time() - t0
+    note(f"{name}: {batch} gates in {dt:.2f} s")
+    po = O.KmsParams(**{f: getattr(p, f) for f, _ in O.KmsParams._fields_})
+    orc = O.KMSOracle(po, K.gsw, K.uni, K.pk, K.crs, K.ksk)
+    O.lib().oracle_set_threads(min(oracle_gates, O.usable_cpus()))
+    stop = threading.Event()
+    threading.Thread(target=lambda: [note(f"{name}: oracle gate(s) still running") for _ in iter(lambda: stop.wait(120), True)], daemon=True).start()
+    t0 = time.time()
+    ref = orc.gates(O.NAND, xa[:oracle_gates], xb[:oracle_gates])
+    t_or = time.time() - t0
+    stop.set()
+    emit(check=name, workload=f"{batch} mk_gate_nand_new, {name} at full size (P={p.parties}, n={p.n}, N={p.N}, gsw {p.l_gsw}/{p.bg_gsw}, lev {p.l_lev}/{p.bg_lev}, uni {p.l_uni}/{p.bg_uni})",
+         gates_per_s=batch / dt, seconds=dt, host_keygen_s=t_key, all_decrypt_correct=bool(np.array_equal(K.decrypt(out), ~(a.astype(bool) & b.astype(bool)))),
+         oracle_gates=oracle_gates, oracle_seconds=t_or, words_equal_to_oracle=bool(np.array_equal(out[:oracle_gates], ref)), words_compared=int(ref.size))
     ck.close()
 
 
@@ -207,6 +277,12 @@ CHECKS = {
     "mk512": lambda: mk_timing_synthetic("MK512", 256, parties=int(os.environ.get("MK512_PARTIES", "128"))),
     "ccs16": ccs16_check,
     "mk64fft-oracle": lambda: mk_oracle_keys_check("MK64-fft", 64, 1),
+    "ccs2-oracle": lambda: ccs_oracle_check("CCS2", 256, 8),
+    "ccs4-oracle": lambda: ccs_oracle_check("CCS4", 128, 4),
+    "ccs8-oracle": lambda: ccs_oracle_check("CCS8", 64, 2),
+    "ccs16-oracle": lambda: ccs_oracle_check("CCS16", 32, 1),
+    "kms4": lambda: kms_check("KMS4", 64, 2),
+    "kms8": lambda: kms_check("KMS8", 32, 1),
 }
 
 if __name__ == "__main__":

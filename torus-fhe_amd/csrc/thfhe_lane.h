@@ -421,8 +421,23 @@ THFHE_FN size_t bk_spec_index(int i, int r, int c, int h, int rows) {
 
 // t[m] = (X^a * acc_j - acc_j)[lane + 64 m] + offset, m = 0..15      (J/bootstrap.jl:21 + J/tgsw.jl:125-137)
 THFHE_FN void load_rotated16(int lane, const int32_t *acc_poly, int a2n, uint32_t offset, uint32_t (&t)[16]) {
+    // all 32 LDS reads first, the arithmetic after a scheduling fence: left to itself the compiler (in the CCS kernels) read one word, waited for it
+    // (s_waitcnt lgkmcnt(0)), used it and only then read the next -- 32 exposed LDS round trips per digit row
+    uint32_t r[16], s[16];
 #pragma unroll
-    for (int m = 0; m < 16; m++) t[m] = rot_minus_self32(acc_poly, lane + 64 * m, a2n, 1024) + offset;
+    for (int m = 0; m < 16; m++) {
+        const int e = (lane + 64 * m - a2n) & 2047;
+        r[m] = (uint32_t)acc_poly[e & 1023];
+        s[m] = (uint32_t)acc_poly[lane + 64 * m];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const int e = (lane + 64 * m - a2n) & 2047;
+        t[m] = ((e & 1024) ? 0u - r[m] : r[m]) - s[m] + offset;      // = rot_minus_self32(acc_poly, lane + 64 m, a2n, 1024) + offset
+    }
 }
 // folded complex input of the level-p digit polynomial (p = 1..l)
 THFHE_FN void digits_to_z(const uint32_t (&t)[16], int p, int Bgbit, cplx (&z)[8]) {
@@ -833,6 +848,26 @@ THFHE_FN uint64_t rot_minus_self64_n(const int64_t *p, int q, int a2n) {
     uint64_t r = (uint64_t)p[e & (NN - 1)];
     if (e & NN) r = 0ull - r;
     return r - (uint64_t)p[q];
+}
+// out[k] = (X^a p - p)[q0 + 64 k], k < K: all 2 K LDS reads first, the sign / subtraction after a scheduling fence (left to itself the compiler reads,
+// waits for and uses one word at a time in the kernels that stage rotated words: K exposed LDS round trips instead of one)
+template <int NN, int K>
+THFHE_FN void rot_minus_self64_batch(const int64_t *p, int q0, int a2n, uint64_t (&out)[K]) {
+    uint64_t r[K], s[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int e = (q0 + 64 * k - a2n) & (2 * NN - 1);
+        r[k] = (uint64_t)p[e & (NN - 1)];
+        s[k] = (uint64_t)p[q0 + 64 * k];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int e = (q0 + 64 * k - a2n) & (2 * NN - 1);
+        out[k] = ((e & NN) ? 0ull - r[k] : r[k]) - s[k];
+    }
 }
 // t[m] = top 32 bits of (X^a acc_j - acc_j)[lane + 64 m] + offset, m = 0..31   (N = 2048)
 THFHE_FN void load_rotated32_hi(int lane, const int64_t *acc_poly, int a2n, uint64_t offset, uint32_t (&t)[32]) {

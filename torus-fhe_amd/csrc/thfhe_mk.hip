@@ -455,16 +455,28 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
                 const int32_t half = 1 << (Bgbit - 1);
                 const int32_t hp = pw ? 1 << (pw - 1) : 0, mp = (1 << pw) - 1;
                 constexpr double R = 0.70710678118654752440;
+                // all 32 rotated words first (their LDS reads in flight together), then the branch-free digit arithmetic: with the loop over the
+                // parts inside the unrolled body every rotated read was waited for on its own (s_waitcnt lgkmcnt(0) + a uniform branch per coefficient)
 #pragma unroll
-                for (int m = 0; m < 8; m++) {
+                for (int m0 = 0; m0 < 8; m0 += 4) {   // in two halves: 16 words alive next to the points already formed (all 32 spilled 56 B per lane)
+                uint32_t t[4][4];
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t[m][q] = (uint32_t)((rot_minus_self64_n<2048>(ap, lane + 64 * (m0 + m) + 512 * q, a2n) + offset) >> 32);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int mm = 0; mm < 4; mm++) {
+                    const int m = m0 + mm;
                     double d[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const uint32_t t = (uint32_t)((rot_minus_self64_n<2048>(ap, lane + 64 * m + 512 * q, a2n) + offset) >> 32);
-                        int32_t dg = (int32_t)((t >> shift) & mask) - half;      // decompose, J/tgsw.jl:112-138
-                        if (parts > 1) {                                            // balanced parts, least significant first
-                            for (int w = 0; w < part; w++) dg = (dg - (((dg + hp) & mp) - hp)) >> pw;
-                            if (part < parts - 1) dg = ((dg + hp) & mp) - hp;
+                        int32_t dg = (int32_t)((t[mm][q] >> shift) & mask) - half;      // decompose, J/tgsw.jl:112-138
+                        if (parts > 1) {   // balanced parts, least significant first; at most three (l x parts <= 3); uniform selects, no branches
+                            const int32_t lo0 = ((dg + hp) & mp) - hp, v1 = (dg - lo0) >> pw;
+                            const int32_t lo1 = ((v1 + hp) & mp) - hp, v2 = (v1 - lo1) >> pw;
+                            const int32_t p1 = parts > 2 ? lo1 : v1;
+                            dg = part == 0 ? lo0 : (part == 1 ? p1 : v2);
                         }
                         d[q] = (double)dg;
                     }
@@ -472,6 +484,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
                     const cplx w{(d[1] - d[3]) * R, (d[1] + d[3]) * R};
                     y0[m] = cplx{d[0] + w.re, d[2] + w.im};
                     y1[m] = cplx{d[0] - w.re, d[2] - w.im};
+                }
                 }
             }
             cplx *xb = sSpec + wave * 1024;
@@ -579,27 +592,37 @@ __device__ __forceinline__ void p2k_stage(int wave, int lane, const int64_t (*sA
         dst[c] = (uint32_t)((rot_minus_self64_n<2048>(ap, c, a2n) + offset) >> 32);
     }
 }
-template <int LE>
+// ONE_PART: the gadget digit is used whole (parts = 1: every set with Bgbit <= 10, e.g. BASELINE configs[4]) -- the per-coefficient part loops and
+// their 32 uniform branches per task are compiled out; the general form serves the wide-base sets (two / three balanced parts).
+template <int LE, bool ONE_PART>
 __device__ __forceinline__ void p2k_pack(int f, int lane, const uint32_t *stage, const P2KDigits &dg, uint32_t (&pk)[8][2]) {
     constexpr int ROWS = 2 * LE;
     const int g = f / ROWS, r = f % ROWS;
     const uint32_t *src = stage + (g * 2 + r / LE) * 2048;
-    const int level = (r % LE) / dg.parts, part = (r % LE) % dg.parts;   // uniform per wave
+    const int level = ONE_PART ? (r % LE) : (r % LE) / dg.parts, part = ONE_PART ? 0 : (r % LE) % dg.parts;   // uniform per wave
     const int shift = 32 - (level + 1) * dg.Bgbit;
     const uint32_t mask = (1u << dg.Bgbit) - 1u;
     const int32_t half = 1 << (dg.Bgbit - 1);
     const int pw = dg.pw;
     const int32_t hp = pw ? 1 << (pw - 1) : 0, mp = (1 << pw) - 1;
+    // all 32 staged words first (independent LDS reads in flight together), then the digit arithmetic -- branch-free: with a loop over the parts
+    // inside the unrolled body every read was followed by s_waitcnt lgkmcnt(0) and a uniform branch (64 exposed LDS round trips per step)
+    uint32_t t[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) t[m][q] = src[lane + 64 * m + 512 * q];
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         int32_t d[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint32_t t = src[lane + 64 * m + 512 * q];
-            int32_t v = (int32_t)((t >> shift) & mask) - half;      // decompose, J/tgsw.jl:112-138
-            if (dg.parts > 1) {                                       // balanced parts, least significant first
-                for (int w = 0; w < part; w++) v = (v - (((v + hp) & mp) - hp)) >> pw;
-                if (part < dg.parts - 1) v = ((v + hp) & mp) - hp;
+            int32_t v = (int32_t)((t[m][q] >> shift) & mask) - half;      // decompose, J/tgsw.jl:112-138
+            if (!ONE_PART) {   // balanced parts, least significant first; at most three (l x parts <= 3)
+                const int32_t lo0 = ((v + hp) & mp) - hp, v1 = (v - lo0) >> pw;
+                const int32_t lo1 = ((v1 + hp) & mp) - hp, v2 = (v1 - lo1) >> pw;
+                const int32_t p0 = dg.parts > 1 ? lo0 : v, p1 = dg.parts > 2 ? lo1 : v1;
+                v = part == 0 ? p0 : (part == 1 ? p1 : v2);
             }
             d[q] = v;
         }
@@ -658,8 +681,13 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
         uint32_t pk0[8][2], pk1[8][2];
         p2k_stage(wave, lane, sAcc, reinterpret_cast<uint32_t *>(sSpec), ai0, ai1, dg.offset);
         lds_barrier<8 * PRE>();
-        if (t0) p2k_pack<LE>(wave, lane, reinterpret_cast<const uint32_t *>(sSpec), dg, pk0);
-        if (t1) p2k_pack<LE>(wave + 8, lane, reinterpret_cast<const uint32_t *>(sSpec), dg, pk1);
+        if (dg.parts == 1) {   // uniform over the launch
+            if (t0) p2k_pack<LE, true>(wave, lane, reinterpret_cast<const uint32_t *>(sSpec), dg, pk0);
+            if (t1) p2k_pack<LE, true>(wave + 8, lane, reinterpret_cast<const uint32_t *>(sSpec), dg, pk1);
+        } else {
+            if (t0) p2k_pack<LE, false>(wave, lane, reinterpret_cast<const uint32_t *>(sSpec), dg, pk0);
+            if (t1) p2k_pack<LE, false>(wave + 8, lane, reinterpret_cast<const uint32_t *>(sSpec), dg, pk1);
+        }
         lds_barrier<8 * PRE>();   // staged words consumed: the slots are free for the spectra
         // ---- half pass 0: even outputs (twist 1); its first key chunks are requested ahead of the transforms (no partial spectra alive yet)
         cplx B[PRE][8];

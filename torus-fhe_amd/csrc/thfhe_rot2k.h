@@ -228,11 +228,10 @@ __device__ __forceinline__ void r2k_stage(int wave, int lane, const int64_t (*sA
     const int cnt = 32 / wpi;              // coefficients per lane: 8 or 16
     const int base = piece * (2048 / wpi) + lane;
     for (int k0 = 0; k0 < cnt; k0 += 8) {
+        uint64_t v[8];
+        rot_minus_self64_batch<2048, 8>(ap, base + 64 * k0, a2n, v);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int c = base + 64 * (k0 + k);
-            dst[c] = rot_minus_self64_n<2048>(ap, c, a2n) + offset;
-        }
+        for (int k = 0; k < 8; k++) dst[base + 64 * (k0 + k)] = v[k] + offset;
     }
 }
 // digits of row part rp of job g for the 32 coefficients this lane transforms, four 16-bit fields per radix-2 group     (decompose, J/tgsw.jl:112-138)

@@ -66,16 +66,24 @@ struct R4KArgs {
 __device__ __forceinline__ void r4k_group_digits(const uint64_t *src, int c, int shift, uint32_t mask, int32_t half, int parts, int part, int pw,
                                                  cplx (&u)[4]) {
     const int32_t hp = pw ? 1 << (pw - 1) : 0, mp = (1 << pw) - 1;
+    // the eight staged words of the group first (their LDS reads in flight together), then branch-free digit arithmetic: a loop over the parts
+    // inside the unrolled body made every read wait on its own (281 of the kernel's 310 LDS waits covered a single read)
+    uint32_t t[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int w = 0; w < 2; w++) t[s][w] = (uint32_t)(src[c + 512 * s + 2048 * w] >> 32);
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         double d[2];
 #pragma unroll
         for (int w = 0; w < 2; w++) {
-            const uint32_t t = (uint32_t)(src[c + 512 * s + 2048 * w] >> 32);
-            int32_t v = (int32_t)((t >> shift) & mask) - half;
-            if (parts > 1) {   // balanced parts, least significant first
-                for (int k = 0; k < part; k++) v = (v - (((v + hp) & mp) - hp)) >> pw;
-                if (part < parts - 1) v = ((v + hp) & mp) - hp;
+            int32_t v = (int32_t)((t[s][w] >> shift) & mask) - half;
+            if (parts > 1) {   // balanced parts, least significant first; at most three; uniform selects
+                const int32_t lo0 = ((v + hp) & mp) - hp, v1 = (v - lo0) >> pw;
+                const int32_t lo1 = ((v1 + hp) & mp) - hp, v2 = (v1 - lo1) >> pw;
+                const int32_t p1 = parts > 2 ? lo1 : v1;
+                v = part == 0 ? lo0 : (part == 1 ? p1 : v2);
             }
             d[w] = (double)v;
         }
@@ -120,11 +128,10 @@ __global__ __launch_bounds__(512, 2) void r4k_rotate_kernel(R4KArgs a, cplx *__r
             {
                 const int j = wave >> 2;
                 const int64_t *ap = sAcc + j * 4096;
+                uint64_t v[16];
+                rot_minus_self64_batch<4096, 16>(ap, (wave & 3) * 1024 + lane, a2n, v);
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const int c = (wave & 3) * 1024 + lane + 64 * k;
-                    stage[j * 4096 + c] = rot_minus_self64_n<4096>(ap, c, a2n) + offset;
-                }
+                for (int k = 0; k < 16; k++) stage[j * 4096 + (wave & 3) * 1024 + lane + 64 * k] = v[k] + offset;
             }
             lds_barrier<0>();
             // ---- digits + radix-4 combination of this wave's tasks (in registers), then the staged words may be overwritten
