@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void ccs_blind_rotate_kernel(CCSArgs a) {
     const long job = blockIdx.x;
     const int P = a.parties, L = a.l, Bgbit = a.Bgbit;
     const int G = 8 / L < 4 ? 8 / L : 4;  // polynomial groups per batch: G*L <= 8 forward transforms, 4*G <= 16 stage-1 output tasks
-    const int32_t *bara = a.bara + job * a.w_pad;
+    const uniform_i32_ptr bara = as_uniform(a.bara + job * a.w_pad);
     const uint32_t offset = decomp_offset32(L, Bgbit);
     for (int q = threadIdx.x; q < (P + 1) * 1024; q += 512) {
         int32_t v = 0;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void ccs_blind_rotate_wide_kernel(CCSArgs a
     const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
     const long job = blockIdx.x;
     const int P = a.parties, L = a.l, Bgbit = a.Bgbit;
-    const int32_t *bara = a.bara + job * a.w_pad;
+    const uniform_i32_ptr bara = as_uniform(a.bara + job * a.w_pad);
     const uint32_t offset = decomp_offset32(L, Bgbit);
     int32_t *V = vbuf + (size_t)job * (P + 1) * 1024;
     for (int q = threadIdx.x; q < (P + 1) * 1024; q += 512) {

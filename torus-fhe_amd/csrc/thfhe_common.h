@@ -86,6 +86,12 @@ __device__ __forceinline__ void wave_fft_inv(int lane, cplx (&z)[8], cplx *xb, c
     wave_sync();
     inv_seg3(lane, z, xb, T1);
 }
+// Wave-uniform words that no kernel of the launch writes (the mod-switched mask words a rotation walks: written by the prologue kernel before it):
+// read through the constant address space, i.e. with s_load_dword into an SGPR.  As plain global loads they were global_load_dword + s_waitcnt vmcnt(0)
+// at the top of every CMux -- a vector-memory round trip on the sequential chain, and a vmcnt(0) that also waits for whatever the wave has in flight.
+typedef const int32_t __attribute__((address_space(4))) *uniform_i32_ptr;
+__device__ __forceinline__ uniform_i32_ptr as_uniform(const int32_t *p) { return (uniform_i32_ptr)(size_t)p; }
+
 // ---- LDS key ring (shared by the single-key and multi-key ring kernels) --------------------------------------------
 // One LDS-DMA of this wave's 1 KiB slice of a key chunk: lane l fetches 16 B at gptr_lane into LDS at lds_byte_off + 16 l.
 // Inline asm on purpose: the compiler then neither waits vmcnt(0) before every ring read nor reorders the hand-off.  The LDS base

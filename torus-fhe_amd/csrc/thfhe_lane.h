@@ -471,20 +471,34 @@ THFHE_FN void rotated_digits_z(int lane, const int32_t *p, int a2n, int level, i
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t base = (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)p;   // LDS, 4 KiB-aligned (the kernels' sAcc)
 #endif
+    // all 32 LDS reads first (rotated word and own word of the 16 coefficients), the arithmetic after a scheduling fence: the compiler otherwise
+    // chains them -- read, s_waitcnt lgkmcnt(0), use, next read -- and the latency kernel's forward phase carried a dozen exposed LDS round trips
+    uint32_t r[8][2], s[8][2];
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-        double d[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int c = lane + 64 * m + 512 * q;          // coefficient index
             const uint32_t f = e4 + (uint32_t)(256 * m + 2048 * q);
 #if defined(__HIP_DEVICE_COMPILE__)
-            const uint32_t r = (uint32_t) * (__attribute__((address_space(3))) const int32_t *)(size_t)(base | (f & 0xFFCu));
+            r[m][q] = (uint32_t) * (__attribute__((address_space(3))) const int32_t *)(size_t)(base | (f & 0xFFCu));
 #else
-            const uint32_t r = (uint32_t)p[(f & 0xFFCu) >> 2];
+            r[m][q] = (uint32_t)p[(f & 0xFFCu) >> 2];
 #endif
+            s[m][q] = (uint32_t)p[c];
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        double d[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t f = e4 + (uint32_t)(256 * m + 2048 * q);
             const uint32_t M = (uint32_t)sbfe32(f, 12, 1);   // -1 where X^a wraps with a sign flip
-            const uint32_t v = ((r + M) ^ M) + (off - (uint32_t)p[c]);
+            const uint32_t v = ((r[m][q] + M) ^ M) + (off - s[m][q]);
             d[q] = (double)sbfe32(v, shift, Bgbit);
         }
         z[m] = cplx{d[0], d[1]};
@@ -508,12 +522,37 @@ THFHE_FN uint32_t rotated_word(int lane, const int32_t *p, uint32_t e4, int j, u
     const uint32_t M = (uint32_t)sbfe32(f, 12, 1);
     return ((r + M) ^ M) + (off - (uint32_t)p[lane + 64 * j]);
 }
-template <int NF>
+// BATCH: all 2 NF LDS reads first, the arithmetic after a scheduling fence.  The eight-wave ring kernel's schedule already keeps the reads together;
+// in its four-wave shape (one wave per SIMD, nobody to cover a round trip) the compiler chained them: read, s_waitcnt lgkmcnt(0), use, next read.
+template <int NF, bool BATCH = false>
 THFHE_FN void rotated_fields_keep(int lane, const int32_t *p, int a2n, int l, int Bgbit, uint32_t (&t)[NF]) {
     const uint32_t off = decomp_offset32(l, Bgbit);
     const uint32_t e4 = ((uint32_t)(lane - a2n) & 2047u) << 2;
+    if (!BATCH) {
 #pragma unroll
-    for (int j = 0; j < NF; j++) t[j] = rotated_word(lane, p, e4, j, off) ^ off;
+        for (int j = 0; j < NF; j++) t[j] = rotated_word(lane, p, e4, j, off) ^ off;
+        return;
+    }
+    uint32_t r[NF], s[NF];
+#pragma unroll
+    for (int j = 0; j < NF; j++) {
+        const uint32_t f = e4 + (uint32_t)(256 * j);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t base = (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)p;   // LDS, 4 KiB-aligned
+        r[j] = (uint32_t) * (__attribute__((address_space(3))) const int32_t *)(size_t)(base | (f & 0xFFCu));
+#else
+        r[j] = (uint32_t)p[(f & 0xFFCu) >> 2];
+#endif
+        s[j] = (uint32_t)p[lane + 64 * j];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int j = 0; j < NF; j++) {
+        const uint32_t M = (uint32_t)sbfe32(e4 + (uint32_t)(256 * j), 12, 1);
+        t[j] = (((r[j] + M) ^ M) + (off - s[j])) ^ off;
+    }
 }
 template <int NF>
 THFHE_FN void mixed_digits_z(int lane, const int32_t *p, int a2n, int level, int l, int Bgbit, const uint32_t (&t)[NF], cplx (&z)[8]) {

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void sk_blind_rotate_ring_k
     const bool has_job = job < a.jobs;
     int32_t *acc = sAcc[wave];
     cplx *xb = sX[wave];
-    const int32_t *bara = a.bara + (has_job ? job : 0) * a.n_pad;
+    const uniform_i32_ptr bara = as_uniform(a.bara + (has_job ? job : 0) * a.n_pad);   // job is wave-uniform: scalar loads
     const int Bgbit = a.Bgbit;
     if (has_job) acc_init16(lane, acc, acc + 1024, a.barb[job], a.mu);
 
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void sk_blind_rotate_ring_k
                 // index / sign / subtraction once per accumulator polynomial, then one signed bit-field extract + one conversion per level
                 int a2n_r = a2n;
                 asm volatile("" : "+s"(a2n_r));  // opaque per row: the rotated LDS addresses are recomputed, not kept alive
-                if (r % L == 0) rotated_fields_keep<NF>(lane, acc + (r / L) * 1024, a2n_r, L, Bgbit, fld);
+                if (r % L == 0) rotated_fields_keep<NF, W == 4>(lane, acc + (r / L) * 1024, a2n_r, L, Bgbit, fld);
                 asm volatile("" : "+s"(a2n_r));
                 mixed_digits_z<NF>(lane, acc + (r / L) * 1024, a2n_r, (r % L) + 1, L, Bgbit, fld, z);
                 if (V & 1) wave_fft_fwd_q(lane, z, xb, tw, w64); else wave_fft_fwd_r(lane, z, xb, roots, w64);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void sk_blind_rotate_coop_kernel(BRArgs a) 
     const W64 w64{a.tw[512 + 1 * 8 + (lane & 7)]};
     const LaneRoots roots{a.tw[576 + 2 * lane], a.tw[576 + 2 * lane + 1]};
     const long job = blockIdx.x;
-    const int32_t *bara = a.bara + job * a.n_pad;
+    const uniform_i32_ptr bara = as_uniform(a.bara + job * a.n_pad);
     const int Bgbit = a.Bgbit;
     if (wave == 0) acc_init16(lane, sAcc, sAcc + 1024, a.barb[job], a.mu);
     const int c = (wave >> 1) & 1, h = wave & 1, half = wave >> 2, r0 = half * L;  // role in M: rows r0 .. r0+L-1 of (column c, limb h)
