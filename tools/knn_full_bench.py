@@ -85,9 +85,11 @@ if Q > 1:
             ok &= dec(res["count"][q]) == votes and bool(KS.decrypt(res["decision"][q][None])[0]) == (votes > threshold)
         s1, s2 = st["phase1"], st["phase2"]
         mine = max(len(st["my_queries"]), 1)
-        rot = Q * (s1.get("rotations", 0) + s2.get("rotations", 0)) // mine
+        once = (s1.get("copies_once") or {}).get("rotations") or 0          # the train rows' MUX copies: evaluated once per rank, not once per test record
+        per_query = (s1.get("rotations", 0) - once + s2.get("rotations", 0)) // mine
+        rot = Q * per_query + world * once                                   # rotations actually evaluated by all ranks
         print(json.dumps(dict(workload=f"{Q} KNN decisions (test records) as instances of one DAG, {NTRAIN} train rows x {NCOL} columns x {NB} bit (reference circuit)",
-                              n_gpus=world, queries=Q, blind_rotations=rot, seconds=dt, rotations_per_s=rot / dt, seconds_per_decision=dt / Q,
+                              n_gpus=world, queries=Q, blind_rotations=rot, reference_rotations=Q * (per_query + once), seconds=dt, rotations_per_s=rot / dt, seconds_per_decision=dt / Q,
                               levels=dict(phase1=s1.get("levels"), phase2=s2.get("levels")), phase_seconds=dict(phase1=s1.get("seconds"), phase2=s2.get("seconds")),
                               launches=dict(phase1=s1.get("launches"), phase2=s2.get("launches")), sharding="by query", correct=bool(ok))), flush=True)
     sys.exit(0)
