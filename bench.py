@@ -120,8 +120,10 @@ def dist_setup(n_gpus):
     backend = os.environ.get("THFHE_BENCH_BACKEND", "nccl")
     if backend not in ("nccl", "gloo"):
         raise SystemExit(f"[bench] THFHE_BENCH_BACKEND={backend!r}: expected nccl or gloo")
-    if backend == "nccl" and torch.cuda.device_count() < world:
-        # one rank per GPU or nothing: N ranks sharing fewer devices would print an N-GPU line measured on fewer GPUs
+    if backend == "nccl" and 1 < torch.cuda.device_count() < world:
+        # one rank per GPU or nothing: N ranks sharing fewer devices would print an N-GPU line measured on fewer GPUs.  (A launcher that shows every
+        # rank exactly ONE device -- per-rank isolation -- is fine: local % 1 = 0; two ranks that really share a device are refused by RCCL itself,
+        # "duplicate GPU detected", and the line's `distinct_devices` shows what ran where.)
         print(f"[bench] rank {rank}: --gpus {world} over RCCL needs {world} visible GPUs, this node shows {torch.cuda.device_count()}", file=sys.stderr, flush=True)
         raise SystemExit(4)
     # RCCL / gloo print start-up banners on the C-level stdout: keep stdout clean for the single JSON line
