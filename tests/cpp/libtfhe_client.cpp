@@ -139,6 +139,8 @@ int main(int argc, char **argv) {
         printf("fresh_variance: %.6e\n", c[0].current_variance);
         if (c[0].current_variance < 9.3e-10 || c[0].current_variance > 9.33e-10) fail("variance of a fresh ciphertext");
         delete_gate_bootstrapping_ciphertext_array(32, c);
+        delete_gate_bootstrapping_secret_keyset(key);
+        delete_gate_bootstrapping_parameters(params);
         printf("host: ok\n");
         return 0;
     }

@@ -94,6 +94,21 @@ def test_seeded_keygen_reproduces_the_reference_key_and_files(work, O):
     assert abs(err.std() - 2.0**-15) < 0.1 * 2.0**-15 and abs(err.mean()) < 5e-6
 
 
+def test_host_api_under_address_and_ub_sanitizers(tmp_path):
+    """csrc/tfhe_host.cpp builds libtfhe's pointer graphs by hand (key-switching key: 32 768 samples in one block, n TGSW samples sharing four slabs):
+    keygen -> key files -> reload -> import / decrypt / re-export the 11 reference files -> delete everything, under ASan + UBSan with leak detection."""
+    subprocess.run(["make", "-s", "-C", CPP, "libtfhe_client_asan"], check=True)
+    # the parameter set read inside a key file belongs to no caller-visible owner (libtfhe hands it to its garbage collector, which frees it at exit; here it
+    # lives until exit too): 164 bytes per loaded key set, suppressed by name -- everything else must be freed by the delete_* calls
+    supp = tmp_path / "lsan.supp"
+    supp.write_text("leak:read_params\n")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", LSAN_OPTIONS=f"suppressions={supp}:print_suppressions=0")
+    for mode in (["keygen", str(tmp_path)], ["host", str(tmp_path), GOLDEN]):
+        r = subprocess.run([os.path.join(CPP, "libtfhe_client_asan"), *mode], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "ERROR" not in r.stderr and "runtime error" not in r.stderr, (mode[0], r.stderr[-3000:])
+    assert "host: ok" in r.stdout
+
+
 @pytest.mark.gpu
 def test_reference_shaped_program_runs_on_the_gpu(work):
     """32 x bootsAND (src/Convert.cpp:29-33) and the FullAdder (src/bootstrap_modules.cpp:20-44) on the reference's input ciphertexts,
