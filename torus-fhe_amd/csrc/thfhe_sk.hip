@@ -153,6 +153,9 @@ struct BRArgs {
 #ifndef THFHE_RING_NF
 #define THFHE_RING_NF 16
 #endif
+#ifndef THFHE_RING_LEAN_ROOTS
+#define THFHE_RING_LEAN_ROOTS 1   // eight-wave shape: pass-1 twiddles rebuilt per transform (no scratch); 0 = even products kept across the loop
+#endif
 #ifndef THFHE_RING_READ_FIRST
 #define THFHE_RING_READ_FIRST 0   // 1 = round 4's experiment (profiles/r04_ring_multiply_phase.md): measured slower, kept for the record
 #endif
@@ -223,7 +226,13 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void sk_blind_rotate_ring_k
                 if (r % L == 0) rotated_fields_keep<NF, W == 4>(lane, acc + (r / L) * 1024, a2n_r, L, Bgbit, fld);
                 asm volatile("" : "+s"(a2n_r));
                 mixed_digits_z<NF>(lane, acc + (r / L) * 1024, a2n_r, (r % L) + 1, L, Bgbit, fld, z);
-                if (V & 1) wave_fft_fwd_q(lane, z, xb, tw, w64); else wave_fft_fwd_r(lane, z, xb, roots, w64);
+                // pass-1 twiddles: the eight-wave shape rebuilds all eight products b s^k per transform from the two per-lane roots (made opaque so that
+                // they are not hoisted out of the CMux loop): 12 fewer registers live across the loop than with the even products kept (LaneTw), the
+                // compiler then parks nothing in scratch (44 -> 0 B per lane: no reload in front of a row's digits waits for the ring DMAs any more) --
+                // 30.21 -> 29.97 ms per 4096 gates.  The four-wave shape (registers to spare) keeps LaneTw: 9.67 against 9.80 ms per 1024 gates.
+                if (!(V & 1)) wave_fft_fwd_r(lane, z, xb, roots, w64);
+                else if (THFHE_RING_LEAN_ROOTS && W == 8) wave_fft_fwd_q(lane, z, xb, LaneRoots{opaque_cplx(roots.b), opaque_cplx(roots.s)}, w64);
+                else wave_fft_fwd_q(lane, z, xb, tw, w64);
             }
             STAMP(0);
             cplx bA[4], bB[4];
@@ -274,8 +283,13 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void sk_blind_rotate_ring_k
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 if ((V & 1) && !(V & 2)) {
-                    wave_fft_inv_q(lane, S[c][0], xb, tw, w64);
-                    wave_fft_inv_q(lane, S[c][1], xb, tw, w64);
+                    if (THFHE_RING_LEAN_ROOTS && W == 8) {
+                        wave_fft_inv_q(lane, S[c][0], xb, LaneRoots{opaque_cplx(roots.b), opaque_cplx(roots.s)}, w64);
+                        wave_fft_inv_q(lane, S[c][1], xb, LaneRoots{opaque_cplx(roots.b), opaque_cplx(roots.s)}, w64);
+                    } else {
+                        wave_fft_inv_q(lane, S[c][0], xb, tw, w64);
+                        wave_fft_inv_q(lane, S[c][1], xb, tw, w64);
+                    }
                 } else {
                     wave_fft_inv_r(lane, S[c][0], xb, roots, w64);
                     wave_fft_inv_r(lane, S[c][1], xb, roots, w64);
