@@ -274,6 +274,41 @@ __device__ __forceinline__ void wave_fft_inv_tq(int lane, cplx (&z)[8], cplx *xb
     invtq_seg3<T, DEN>(z, r);
 }
 
+// Two transforms of one wave side by side.  A wavefront's DS instructions execute in issue order, so the second transform's arithmetic covers
+// the first one's LDS round trip (and the other way round); the inverse pair shares ONE transpose buffer: the second one's stores may follow
+// the first one's loads without a wait.
+template <int TA, int TB, int DEN = 32>
+__device__ __forceinline__ void wave_fft_fwd_tq_two(int lane, cplx (&za)[8], cplx (&zb)[8], cplx *xa, cplx *xb, const LaneRoots &ra, const LaneRoots &rb,
+                                                    const W64 &w) {
+    fwdtq_seg1<TA, DEN>(za, ra);
+    fwdtq_seg1<TB, DEN>(zb, rb);
+    wave_transpose_hi3(za);
+    wave_transpose_hi3(zb);
+    wave_sync();
+    fwds_seg2_st(lane, za, xa, w);
+    fwds_seg2_st(lane, zb, xb, w);
+    wave_sync();
+    fwds_seg3(lane, za, xa);
+    fwds_seg3(lane, zb, xb);
+}
+template <int TA, int TB, int DEN = 32>
+__device__ __forceinline__ void wave_fft_inv_tq_two(int lane, cplx (&za)[8], cplx (&zb)[8], cplx *xb, const LaneRoots &ra, const LaneRoots &rb, const W64 &w) {
+    wave_sync();
+    invs_seg1(lane, za, xb, w);
+    wave_sync();
+    invs_seg2_ld(lane, za, xb);
+    wave_sync();
+    invs_seg1(lane, zb, xb, w);
+    wave_sync();
+    dft8<-1>(za);
+    wave_transpose_hi3(za);
+    invs_seg2_ld(lane, zb, xb);
+    invtq_seg3<TA, DEN>(za, ra);
+    dft8<-1>(zb);
+    wave_transpose_hi3(zb);
+    invtq_seg3<TB, DEN>(zb, rb);
+}
+
 #endif
 
 }  // namespace thfhe

@@ -391,9 +391,9 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
 // ------------------------------------------------------------------------------------------------------
 // N = 2048 (BASELINE config 5).  Same wave roles as above; every 1024-point transform is a radix-2 split and two twisted
 // 512-point transforms (thfhe_lane.h), so a digit row publishes TWO half spectra (16 KiB) and a phase-2 wave keeps two
-// partial spectra S0 / S1.  LDS at l = 3: T1 tables 16 + accumulator 32 + spectra 96 = 144 KiB, so the transpose buffers
-// alias the spectrum area: in phase 1 wave r transposes inside its own (not yet published) spectrum slot, in phase 2 a third
-// barrier frees the whole area before the eight inverse transforms use 8 KiB of it each.
+// partial spectra S0 / S1.  LDS at l = 3: accumulator 32 + spectra 96 = 128 KiB (table-free "qs" transforms), so the transpose buffers
+// alias the spectrum area: in phase 1 a forward unit transposes inside its own (not yet published) half-spectrum slot, in phase 2 a third
+// barrier frees the whole area before the eight waves' inverse transform pairs use 8 KiB of it each.
 // ------------------------------------------------------------------------------------------------------
 THFHE_STAMP_STORAGE
 __device__ __forceinline__ void mk_pin() { asm volatile("" ::: "memory"); }  // memory operations do not move across this point
@@ -404,13 +404,14 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
     const int parts = a.parts > 1 ? a.parts : 1, pw = a.pw;
     const int L = LE / parts;   // decomposition levels
     constexpr int SPEC_SLOTS = ROWS * 1024 > 8 * 512 ? ROWS * 1024 : 8 * 512;
-    __shared__ cplx sT1[2][512];
     __shared__ int64_t sAcc[4096];
     __shared__ cplx sSpec[SPEC_SLOTS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    for (int t = threadIdx.x; t < 1024; t += 512) (&sT1[0][0])[t] = a.tw[t];
-    const W64 w64{a.tw[1024 + 1 * 8 + (lane & 7)]};
+    // per-lane transform constants are phase-local (L1 / L2 hits at the start of a transform phase), not 10 VGPRs alive across the multiply
+    auto tw_w64 = [&](int ln) { return W64{a.tw[1024 + 1 * 8 + (ln & 7)]}; };
+    auto tw_roots1 = [&](int ln) { return LaneRoots{opaque_cplx(a.tw[ln]), opaque_cplx(a.tw[1216 + ln])}; };   // b_T = T1_T[0][lane], pass-1 ratio
+    auto tw_roots5 = [&](int ln) { return LaneRoots{opaque_cplx(a.tw[512 + ln]), opaque_cplx(a.tw[1216 + ln])}; };
     const long job = blockIdx.x;
     const int32_t *bara = a.bara + job * a.w_pad;
     const int Bgbit = a.Bgbit;
@@ -443,18 +444,24 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
         int inext = i + 1;
         while (inext < a.pn && bara[inext] == 0) inext++;
         const int inl = inext < a.pn ? inext : i;   // the last step re-requests its own chunks (unconditional loads: one register set)
-        if (wave < ROWS) {
-            cplx y0[8], y1[8];
+        // forward units (digit row, half): 2 ROWS of them on eight waves.  ROWS = 6: waves 0 - 3 take both halves of rows 0 - 3 (two transforms side
+        // by side), waves 4 - 7 one half of rows 4 / 5 each -- three units per SIMD (wave w and w + 4 share one); ROWS < 6: one unit per wave
+        const bool two = ROWS == 6 && wave < 4;
+        const int row = ROWS == 6 ? (wave < 4 ? wave : 4 + ((wave - 4) >> 1)) : (wave >> 1);
+        const int half_of = wave & 1;
+        if (ROWS == 6 || wave < 2 * ROWS) {
+            cplx y0[8], y1[8];   // a one-unit wave forms its half in y0
             {
                 // digits of the four coefficients (j, j + 512, j + 1024, j + 1536) that make one (y0[m], y1[m]) pair: no 32-word t[],
                 // no 16-point z[] alive next to the two half transforms
-                const int64_t *ap = sAcc + (wave / LE) * 2048;
-                const int level = (wave % LE) / parts, part = (wave % LE) % parts;   // uniform per wave
+                const int64_t *ap = sAcc + (row / LE) * 2048;
+                const int level = (row % LE) / parts, part = (row % LE) % parts;   // uniform per wave
                 const int shift = 32 - (level + 1) * Bgbit;
                 const uint32_t mask = (1u << Bgbit) - 1u;
                 const int32_t half = 1 << (Bgbit - 1);
                 const int32_t hp = pw ? 1 << (pw - 1) : 0, mp = (1 << pw) - 1;
                 constexpr double R = 0.70710678118654752440;
+                const double sg = half_of ? -1.0 : 1.0;
                 // all 32 rotated words first (their LDS reads in flight together), then the branch-free digit arithmetic: with the loop over the
                 // parts inside the unrolled body every rotated read was waited for on its own (s_waitcnt lgkmcnt(0) + a uniform branch per coefficient)
 #pragma unroll
@@ -482,21 +489,33 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
                     }
                     // z[m] = (d0, d2) (coefficients j, j + 1024), z[m + 8] = (d1, d3); split2048: y0/1 = z[m] +- e^{i pi/4} z[m + 8]
                     const cplx w{(d[1] - d[3]) * R, (d[1] + d[3]) * R};
-                    y0[m] = cplx{d[0] + w.re, d[2] + w.im};
-                    y1[m] = cplx{d[0] - w.re, d[2] - w.im};
+                    if (two) {
+                        y0[m] = cplx{d[0] + w.re, d[2] + w.im};
+                        y1[m] = cplx{d[0] - w.re, d[2] - w.im};
+                    } else {
+                        y0[m] = cplx{d[0] + sg * w.re, d[2] + sg * w.im};   // one rounding, like the sum / difference it stands for
+                    }
                 }
                 }
             }
-            cplx *xb = sSpec + wave * 1024;
-            int ln = lane;
-            asm volatile("" : "+v"(ln));   // the swizzled LDS slot maps are recomputed here, not hoisted out of the CMux loop and spilled
-            wave_fft_fwd_t<1>(ln, y0, xb, sT1[0], w64);
-            wave_fft_fwd_t<5>(ln, y1, xb, sT1[1], w64);
-            wave_sync();
+            cplx *xb = sSpec + row * 1024;
+            const int ln = opaque_lane(lane);   // the swizzled LDS slot maps are recomputed here, not hoisted out of the CMux loop and spilled
+            const W64 w64 = tw_w64(ln);
+            if (two) {
+                wave_fft_fwd_tq_two<1, 5>(ln, y0, y1, xb, xb + 512, tw_roots1(ln), tw_roots5(ln), w64);
+                wave_sync();
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                xb[m * 64 + lane] = y0[m];
-                xb[512 + m * 64 + lane] = y1[m];
+                for (int m = 0; m < 8; m++) {
+                    xb[m * 64 + ln] = y0[m];
+                    xb[512 + m * 64 + ln] = y1[m];
+                }
+            } else {
+                cplx *slot = xb + half_of * 512;
+                if (half_of == 0) wave_fft_fwd_tq<1>(ln, y0, slot, tw_roots1(ln), w64);
+                else wave_fft_fwd_tq<5>(ln, y0, slot, tw_roots5(ln), w64);
+                wave_sync();
+#pragma unroll
+                for (int m = 0; m < 8; m++) slot[m * 64 + ln] = y0[m];
             }
         }
         STAMP(0);
@@ -526,10 +545,8 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
         STAMP(4);
         {
             cplx *xb = sSpec + wave * 512;
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            wave_fft_inv_t<1>(ln, S0, xb, sT1[0], w64);
-            wave_fft_inv_t<5>(ln, S1, xb, sT1[1], w64);
+            const int ln = opaque_lane(lane);
+            wave_fft_inv_tq_two<1, 5>(ln, S0, S1, xb, tw_roots1(ln), tw_roots5(ln), tw_w64(ln));
             cplx lo[8], hi[8];
             merge2048(S0, S1, lo, hi);
 #pragma unroll
@@ -699,8 +716,12 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
             const int ln = opaque_lane(lane);
             const W64 w64 = tw_w64(ln);
             const LaneRoots roots1 = tw_roots1(ln);
-            if (t0) r2k_transform<0>(wave, lane, sSpec, pk0, roots1, w64);
-            if (t1) r2k_transform<0>(wave + 8, lane, sSpec, pk1, roots1, w64);
+            if (t0 && t1) {
+                r2k_transform_two<0>(wave, wave + 8, lane, sSpec, pk0, pk1, roots1, w64);
+            } else {
+                if (t0) r2k_transform<0>(wave, lane, sSpec, pk0, roots1, w64);
+                if (t1) r2k_transform<0>(wave + 8, lane, sSpec, pk1, roots1, w64);
+            }
         }
         STAMP(0);
         lds_barrier<8 * PRE>();   // spectra published
@@ -733,8 +754,12 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
             const int ln = opaque_lane(lane);
             const W64 w64 = tw_w64(ln);
             const LaneRoots roots5 = tw_roots5(ln);
-            if (t0) r2k_transform<1>(wave, lane, sSpec, pk0, roots5, w64);
-            if (t1) r2k_transform<1>(wave + 8, lane, sSpec, pk1, roots5, w64);
+            if (t0 && t1) {
+                r2k_transform_two<1>(wave, wave + 8, lane, sSpec, pk0, pk1, roots5, w64);
+            } else {
+                if (t0) r2k_transform<1>(wave, lane, sSpec, pk0, roots5, w64);
+                if (t1) r2k_transform<1>(wave + 8, lane, sSpec, pk1, roots5, w64);
+            }
         }
         mk_pin();
 #pragma unroll
@@ -772,10 +797,23 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
             const int ln = opaque_lane(lane);
             const W64 w64 = tw_w64(ln);
             const LaneRoots roots1 = tw_roots1(ln), roots5 = tw_roots5(ln);
+            const bool both = ai0 != 0 && ai1 != 0;   // all but one step in 4096: both jobs' transforms of a twist run side by side
+            if (both) {
+                {
+                    const LaneRoots r{opaque_cplx(roots1.b), opaque_cplx(roots1.s)};
+                    wave_fft_inv_tq_two<1, 1>(ln, S0a, S0b, xb, r, r, w64);
+                }
+                {
+                    const LaneRoots r{opaque_cplx(roots5.b), opaque_cplx(roots5.s)};
+                    wave_fft_inv_tq_two<5, 5>(ln, S1a, S1b, xb, r, r, w64);
+                }
+            }
             if (ai0 != 0) {
                 unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[0]) + o * 2048;
-                wave_fft_inv_tq<1>(ln, S0a, xb, LaneRoots{opaque_cplx(roots1.b), opaque_cplx(roots1.s)}, w64);
-                wave_fft_inv_tq<5>(ln, S1a, xb, LaneRoots{opaque_cplx(roots5.b), opaque_cplx(roots5.s)}, w64);
+                if (!both) {
+                    wave_fft_inv_tq<1>(ln, S0a, xb, LaneRoots{opaque_cplx(roots1.b), opaque_cplx(roots1.s)}, w64);
+                    wave_fft_inv_tq<5>(ln, S1a, xb, LaneRoots{opaque_cplx(roots5.b), opaque_cplx(roots5.s)}, w64);
+                }
                 cplx lo[8], hi[8];
                 merge2048(S0a, S1a, lo, hi);
 #pragma unroll
@@ -789,8 +827,10 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair2k_kernel(MKBRArgs
             }
             if (ai1 != 0) {
                 unsigned long long *accu = reinterpret_cast<unsigned long long *>(sAcc[1]) + o * 2048;
-                wave_fft_inv_tq<1>(ln, S0b, xb, LaneRoots{opaque_cplx(roots1.b), opaque_cplx(roots1.s)}, w64);
-                wave_fft_inv_tq<5>(ln, S1b, xb, LaneRoots{opaque_cplx(roots5.b), opaque_cplx(roots5.s)}, w64);
+                if (!both) {
+                    wave_fft_inv_tq<1>(ln, S0b, xb, LaneRoots{opaque_cplx(roots1.b), opaque_cplx(roots1.s)}, w64);
+                    wave_fft_inv_tq<5>(ln, S1b, xb, LaneRoots{opaque_cplx(roots5.b), opaque_cplx(roots5.s)}, w64);
+                }
                 cplx lo[8], hi[8];
                 merge2048(S0b, S1b, lo, hi);
 #pragma unroll

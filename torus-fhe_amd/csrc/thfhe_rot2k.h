@@ -210,6 +210,34 @@ __device__ __forceinline__ void r2k_transform(int f, int lane, cplx *sSpec, cons
     for (int m = 0; m < 8; m++) slot[m * 64 + ln] = y[m];
 }
 
+// two forward tasks of one wave, step by step next to each other: the second task's arithmetic fills the first one's LDS round trips
+template <int HALF>
+__device__ __forceinline__ void r2k_transform_two(int f0, int f1, int lane, cplx *sSpec, const uint32_t (&pk0)[8][2], const uint32_t (&pk1)[8][2],
+                                                  const LaneRoots &roots, const W64 &w64) {
+    constexpr double R = 0.70710678118654752440;
+    constexpr int T = HALF == 0 ? 1 : 5;
+    cplx y0[8], y1[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const double a0 = (double)((int32_t)(pk0[m][0] << 16) >> 16), a1 = (double)((int32_t)pk0[m][0] >> 16);
+        const double a2 = (double)((int32_t)(pk0[m][1] << 16) >> 16), a3 = (double)((int32_t)pk0[m][1] >> 16);
+        const double b0 = (double)((int32_t)(pk1[m][0] << 16) >> 16), b1 = (double)((int32_t)pk1[m][0] >> 16);
+        const double b2 = (double)((int32_t)(pk1[m][1] << 16) >> 16), b3 = (double)((int32_t)pk1[m][1] >> 16);
+        const cplx wa{(a1 - a3) * R, (a1 + a3) * R}, wb{(b1 - b3) * R, (b1 + b3) * R};
+        y0[m] = HALF == 0 ? cplx{a0 + wa.re, a2 + wa.im} : cplx{a0 - wa.re, a2 - wa.im};
+        y1[m] = HALF == 0 ? cplx{b0 + wb.re, b2 + wb.im} : cplx{b0 - wb.re, b2 - wb.im};
+    }
+    const int ln = opaque_lane(lane);
+    cplx *slot0 = sSpec + f0 * 512, *slot1 = sSpec + f1 * 512;
+    const LaneRoots r{opaque_cplx(roots.b), opaque_cplx(roots.s)};
+    wave_fft_fwd_tq_two<T, T>(ln, y0, y1, slot0, slot1, r, r, w64);
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < 8; m++) slot0[m * 64 + ln] = y0[m];
+#pragma unroll
+    for (int m = 0; m < 8; m++) slot1[m * 64 + ln] = y1[m];
+}
+
 struct R2KDigits {
     int lg, bg, parts, lo_bits;
     uint64_t offset;
