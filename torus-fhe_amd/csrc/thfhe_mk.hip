@@ -397,6 +397,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_pair_kernel(MKBRArgs a
 // ------------------------------------------------------------------------------------------------------
 THFHE_STAMP_STORAGE
 __device__ __forceinline__ void mk_pin() { asm volatile("" ::: "memory"); }  // memory operations do not move across this point
+__device__ __forceinline__ void lds_barrier_any() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // workgroup barrier ordering LDS traffic only
 
 template <int LE>   // LE = l x parts: digit rows per accumulator polynomial
 __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs a) {
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
     constexpr int SPEC_SLOTS = ROWS * 1024 > 8 * 512 ? ROWS * 1024 : 8 * 512;
     __shared__ int64_t sAcc[4096];
     __shared__ cplx sSpec[SPEC_SLOTS];
+    __shared__ cplx sXb[4 * 512];   // transpose scratch of waves 0 - 3 (the last 32 KiB of the LDS)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     // per-lane transform constants are phase-local (L1 / L2 hits at the start of a transform phase), not 10 VGPRs alive across the multiply
@@ -430,6 +432,10 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
     // requested two ahead of their use (registers bA / bB), and the first two chunks of the NEXT step are requested before this
     // step's inverse transforms, so the memory pipeline never waits for the compute phases and the multiply never waits for a
     // round trip of its own.  Compiler fences (mk_pin) keep the requests where they are written.
+    // The step loop exists twice, for waves 0 - 3 (EARLY) and 4 - 7: the same phases with the "spectra consumed" barrier behind / in front of
+    // the inverse transforms.  One loop with the barrier under a wave test made the register allocator spill 200 - 2 500 B per lane.
+    auto steps = [&](auto early_tag) {
+    constexpr bool EARLY = decltype(early_tag)::value;
     int i = 0;
     while (i < a.pn && bara[i] == 0) i++;
     cplx bA[8], bB[8];
@@ -541,10 +547,7 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
             mk_pin();
         }
         STAMP(2);
-        __syncthreads();  // spectra consumed: the area is transpose scratch from here on
-        STAMP(4);
-        {
-            cplx *xb = sSpec + wave * 512;
+        auto finish = [&](cplx *xb) {   // inverse transform pair, radix-2 merge, round(S) << 16h into accumulator polynomial o
             const int ln = opaque_lane(lane);
             wave_fft_inv_tq_two<1, 5>(ln, S0, S1, xb, tw_roots1(ln), tw_roots5(ln), tw_w64(ln));
             cplx lo[8], hi[8];
@@ -557,13 +560,30 @@ __global__ __launch_bounds__(512, 2) void mk_blind_rotate_coop2k_kernel(MKBRArgs
                 atomicAdd(accu + q + 1024, (unsigned long long)round_i64(lo[m].im) << (16 * h));
                 atomicAdd(accu + q + 1536, (unsigned long long)round_i64(hi[m].im) << (16 * h));
             }
+        };
+        // The older wave of every SIMD (0 - 3) is served first by the key stream and leaves the multiply ~6 k cycles before its partner.  It owns
+        // 8 KiB of transpose scratch outside the spectrum area, so it does not wait for the others to finish reading the spectra: it
+        // transforms at once and ARRIVES at that barrier afterwards, about when the younger waves get there from their multiply; those then
+        // transform with a SIMD to themselves.  (The accumulator atomics touch nothing the multiply reads.)
+        if (EARLY) {
+            STAMP(4);
+            finish(sXb + wave * 512);
+            STAMP(3);
+            __syncthreads();  // spectra consumed (reached after the transforms)
+        } else {
+            __syncthreads();  // spectra consumed: the area is transpose scratch from here on
+            STAMP(4);
+            finish(sSpec + wave * 512);
+            STAMP(3);
         }
-        STAMP(3);
         __syncthreads();  // accumulator updated and scratch free before the next rotation
         STAMP(5);
         i = inext;
     }
     STAMP_FLUSH(blockIdx.x, wave);
+    };
+    if (wave < 4) steps(std::true_type{});
+    else steps(std::false_type{});
     if (a.acc_out) {
         for (int q = threadIdx.x; q < 4096; q += 512) a.acc_out[job * 4096 + q] = sAcc[q];
     } else if (wave == 0) {
