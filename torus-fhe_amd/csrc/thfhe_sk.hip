@@ -640,6 +640,150 @@ __global__ __launch_bounds__(256) void sk_keyswitch_multi_kernel(KSArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// key switch, staged variant (ks_basebit == 2, t a multiple of 4 and <= 8, W <= 10, >= 1 024 gates).  The kernel above selects a row per gate with
+// wave-uniform branches; the compiler turns that chain into flag-guarded blocks with subtract-into-a-copy + moves, and the loop runs at a
+// quarter of its subtraction rate.  Here the digit selects an ADDRESS: a workgroup of eight waves copies the rows KS[i][j][1..3] of four
+// (i, j) at a time into LDS (twelve contiguous rows in global memory; double buffered through registers), and a lane reads its part of the
+// row its gate's digit names -- digit 0 names a row of zeros -- with ds_read_b128: no branch, no select, 3/32 rows per gate and (i, j)
+// out of L2.  A wave takes FOUR gates, one per 16-lane group of the LDS hardware ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32
+// serve one ds_read_b128 cycle each): the 16 lanes of a group read 16 consecutive pieces of ONE row = all 64 banks once, whatever the four
+// digits are (eight lanes per gate met other gates' rows in their group: two-way conflicts, 1.3 ms per 4096 gates).  Partial sums of the
+// coordinate ranges meet in the zeroed output with integer atomics (adds commute: bit-exact).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ks_sub(uint32_t &r, uint32_t x) { asm("v_sub_u32 %0, %0, %1" : "+v"(r) : "v"(x)); }   // in place, never re-associated
+#ifndef THFHE_KS_CHUNK
+#define THFHE_KS_CHUNK 5
+#endif
+template <int W>
+__global__ __launch_bounds__(512) void sk_keyswitch_staged_kernel(KSArgs a) {
+    constexpr int ROW4 = 16 * W;             // 16-byte pieces of a padded row
+    constexpr int Q = W;                     // pieces per lane: sixteen lanes share a row
+    constexpr int GW = 32, SJ = 4;           // gates per workgroup, (i, j) pairs per stage
+    constexpr int KS_CHUNK = THFHE_KS_CHUNK;
+    constexpr int STAGE4 = SJ * 3 * ROW4;
+    constexpr int NLD = (STAGE4 + 511) / 512;
+    static_assert(NLD <= 4, "a stage is at most four rounds of 512 pieces");
+    __shared__ uint4 sL[ROW4 + 2 * STAGE4];     // [row of zeros][stage 0][stage 1]
+    __shared__ uint16_t sDig[GW][256];          // the t <= 8 digits of every coordinate of this workgroup's range: top 16 bits of u + offset
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int q5 = lane & 31;
+    const int gl = 2 * (lane >> 5) + (int)((0xF00F0FF0u >> q5) & 1u);   // the lane's ds_read_b128 group = its gate within the wave
+    const int c = q5 < 4 ? q5 : q5 < 12 ? q5 - 4 : q5 < 20 ? q5 - 8 : q5 < 28 ? q5 - 12 : q5 - 16;   // position in the group: 0 .. 15
+    const long g0 = (long)blockIdx.x * GW;
+    const int span = 1024 / a.nsplit, first = (int)blockIdx.y * span;   // span <= 256
+    const uint32_t prec_offset = 1u << (32 - (1 + 2 * a.t));
+    for (int q = tid; q < GW * span; q += 512) {
+        const int g = q / span, ii = q % span;
+        uint32_t v = 0;
+        if (g0 + g < a.gates) {
+            const int32_t *u1 = a.u + (size_t)(g0 + g) * a.rot_per_gate * 1025;
+            v = (uint32_t)u1[first + ii];
+            if (a.rot_per_gate == 2) v += (uint32_t)u1[1025 + first + ii];
+            v += prec_offset;
+        }
+        sDig[g][ii] = (uint16_t)(v >> 16);  // absent gates: all digits zero
+    }
+    for (int q = tid; q < ROW4; q += 512) sL[q] = uint4{0u, 0u, 0u, 0u};
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.ksk) + (size_t)first * a.t * 3 * ROW4;
+    const int NS = span * a.t / SJ;
+    // stage st of the key: twelve contiguous rows; thread tid moves pieces tid + 512 k (a partial last round reads a clamped index and stores nothing).
+    // Named scalars: as arrays behind an unrolled loop the pieces stayed in scratch memory.
+    uint4 pre0, pre1 = uint4{0u, 0u, 0u, 0u}, pre2 = pre1, pre3 = pre1;
+    const bool last_ok = 512 * NLD <= STAGE4 || tid + 512 * (NLD - 1) < STAGE4;
+    const int last_idx = last_ok ? tid + 512 * (NLD - 1) : STAGE4 - 1;
+#define KS_GLOAD(st)                                              \
+    {                                                             \
+        const uint4 *p_ = src + (size_t)(st) * STAGE4;            \
+        pre0 = p_[NLD == 1 ? last_idx : tid];                     \
+        if (NLD > 1) pre1 = p_[NLD == 2 ? last_idx : tid + 512];  \
+        if (NLD > 2) pre2 = p_[NLD == 3 ? last_idx : tid + 1024]; \
+        if (NLD > 3) pre3 = p_[last_idx];                         \
+    }
+#define KS_LSTORE(buf)                                                    \
+    {                                                                     \
+        uint4 *d_ = sL + ROW4 + (buf) * STAGE4 + tid;                     \
+        if (NLD > 1 || last_ok) d_[0] = pre0;                             \
+        if (NLD > 2 || (NLD == 2 && last_ok)) d_[512] = pre1;             \
+        if (NLD > 3 || (NLD == 3 && last_ok)) d_[1024] = pre2;            \
+        if (NLD == 4 && last_ok) d_[1536] = pre3;                         \
+    }
+    KS_GLOAD(0)
+    KS_LSTORE(0)
+    __syncthreads();
+    uint4 acc[Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) acc[k] = uint4{0u, 0u, 0u, 0u};
+    const uint16_t *dig = sDig[wave * 4 + gl];
+    for (int st = 0; st < NS; st++) {
+        if (st + 1 < NS) {
+            KS_GLOAD(st + 1)
+        }
+        const int p0 = st * SJ, ii = p0 / a.t, j0 = p0 % a.t;   // t is a multiple of SJ: the pairs of a stage belong to one coordinate
+        const uint32_t hi = dig[ii];
+        const uint4 *row[SJ];
+#pragma unroll
+        for (int pp = 0; pp < SJ; pp++) {
+            const uint32_t d = (hi >> (14 - 2 * (j0 + pp))) & 3u;
+            row[pp] = sL + (d ? ROW4 + (st & 1) * STAGE4 + (pp * 3 + (int)d - 1) * ROW4 : 0) + c;
+        }
+        // KS_CHUNK reads in flight behind the KS_CHUNK being subtracted -- not all of a stage: the memory fence stops the optimiser, the
+        // scheduling barrier the instruction scheduler from clustering them
+        constexpr int NCH = (Q + KS_CHUNK - 1) / KS_CHUNK;
+        uint4 x[2][KS_CHUNK];
+        auto reads = [&](int ch) {   // ch < SJ * NCH, compile-time after unrolling
+            const uint4 *r = row[ch / NCH];
+            const int k0 = (ch % NCH) * KS_CHUNK;
+#pragma unroll
+            for (int k = 0; k < KS_CHUNK; k++)
+                if (k0 + k < Q) x[ch & 1][k] = r[16 * (k0 + k)];
+        };
+        reads(0);
+#pragma unroll
+        for (int ch = 0; ch < SJ * NCH; ch++) {
+            if (ch + 1 < SJ * NCH) reads(ch + 1);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const int k0 = (ch % NCH) * KS_CHUNK;
+#pragma unroll
+            for (int k = 0; k < KS_CHUNK; k++)
+                if (k0 + k < Q) {
+                    uint4 &t = acc[k0 + k];
+                    const uint4 v = x[ch & 1][k];
+                    ks_sub(t.x, v.x), ks_sub(t.y, v.y), ks_sub(t.z, v.z), ks_sub(t.w, v.w);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (st + 1 < NS) {
+            KS_LSTORE((st + 1) & 1)
+        }
+        __syncthreads();
+    }
+#undef KS_GLOAD
+#undef KS_LSTORE
+    const long g = g0 + wave * 4 + gl;
+    if (g < a.gates) {
+        const int32_t *u1 = a.u + (size_t)g * a.rot_per_gate * 1025;
+        unsigned int *out = reinterpret_cast<unsigned int *>(a.out) + (size_t)g * (a.n + 1);
+        uint32_t b = 0;
+        if (blockIdx.y == 0) {
+            b = (uint32_t)u1[1024];
+            if (a.rot_per_gate == 2) b += (uint32_t)u1[1025 + 1024] + (1u << 29);
+        }
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            const uint32_t v4[4] = {acc[k].x, acc[k].y, acc[k].z, acc[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int col = 4 * (c + 16 * k) + e;
+                uint32_t v = v4[e];
+                if (col == a.n) v += b;
+                if (col <= a.n) atomicAdd(out + col, v);
+            }
+        }
+    }
+}
+
 inline int ks_words_per_lane(int n) { return (((n + 1 + 63) / 64) + 1) & ~1; }
 
 __global__ __launch_bounds__(256) void sk_linear_kernel(const int32_t *__restrict__ in0, int32_t *__restrict__ out, size_t words, int negate) {
@@ -660,6 +804,7 @@ struct thfhe_ctx {
     int32_t *d_ksk = nullptr; // padded rows
     int ks_w = 0;             // words per lane of a padded KSK row
     long ks_multi_min_gates = 1024;  // batches of at least this many gates use sk_keyswitch_multi_kernel (rows shared by the gates of a workgroup)
+    bool ks_staged = true;           // ... or, where its shape allows, sk_keyswitch_staged_kernel (rows staged in LDS, the digit selects an address)
     int coop_max_jobs = 768;    // remainders (batch mod 2048) up to this many rotations use the cooperative (latency) kernel
     int ring4_max_jobs = 1024;  // ... above it and up to this many, the four-wave ring kernel (launch_br)
     cplx *d_tw = nullptr;
@@ -799,6 +944,15 @@ int enqueue_keyswitch(thfhe_ctx *c, const int32_t *d_u, int32_t *d_out, size_t g
         KSArgs k{c->d_ksk, d_u, d_out, (long)gates, rot_per_gate, c->p.n, c->p.ks_t, 2, kSplit};
         THFHE_HIP(hipMemsetAsync(d_out, 0, gates * (size_t)(c->p.n + 1) * sizeof(int32_t), c->stream));
         const dim3 block(256);
+        if (c->ks_staged && (c->ks_w == 8 || c->ks_w == 10) && c->p.ks_t <= 8 && c->p.ks_t % 4 == 0) {
+#ifndef THFHE_KS_SPLIT
+#define THFHE_KS_SPLIT 16
+#endif
+            k.nsplit = THFHE_KS_SPLIT;   // 16 coordinate ranges: 2 048 workgroups at 4 096 gates, 512 at 1 024
+            const dim3 sgrid((unsigned)((gates + 31) / 32), THFHE_KS_SPLIT), sblock(512);
+            if (c->ks_w == 8) hipLaunchKernelGGL((sk_keyswitch_staged_kernel<8>), sgrid, sblock, 0, c->stream, k);
+            else hipLaunchKernelGGL((sk_keyswitch_staged_kernel<10>), sgrid, sblock, 0, c->stream, k);
+        } else
         if (c->ks_w == 8) hipLaunchKernelGGL((sk_keyswitch_multi_kernel<2, 0, 8>), dim3((unsigned)((gates + 7) / 8), kSplit), block, 0, c->stream, k);
         else if (c->ks_w == 10) hipLaunchKernelGGL((sk_keyswitch_multi_kernel<2, 1, 8>), dim3((unsigned)((gates + 7) / 8), kSplit), block, 0, c->stream, k);
         else hipLaunchKernelGGL((sk_keyswitch_multi_kernel<4, 1, 4>), dim3((unsigned)((gates + 3) / 4), kSplit), block, 0, c->stream, k);
