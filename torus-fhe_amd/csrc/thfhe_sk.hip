@@ -652,15 +652,12 @@ __global__ __launch_bounds__(256) void sk_keyswitch_multi_kernel(KSArgs a) {
 // coordinate ranges meet in the zeroed output with integer atomics (adds commute: bit-exact).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ks_sub(uint32_t &r, uint32_t x) { asm("v_sub_u32 %0, %0, %1" : "+v"(r) : "v"(x)); }   // in place, never re-associated
-#ifndef THFHE_KS_CHUNK
-#define THFHE_KS_CHUNK 5
-#endif
 template <int W>
 __global__ __launch_bounds__(512) void sk_keyswitch_staged_kernel(KSArgs a) {
     constexpr int ROW4 = 16 * W;             // 16-byte pieces of a padded row
     constexpr int Q = W;                     // pieces per lane: sixteen lanes share a row
     constexpr int GW = 32, SJ = 4;           // gates per workgroup, (i, j) pairs per stage
-    constexpr int KS_CHUNK = THFHE_KS_CHUNK;
+    constexpr int KS_CHUNK = 3;              // reads in flight behind the ones being subtracted (measured: 3 <= 5 < 10; SJ = 2 loses 4 %)
     constexpr int STAGE4 = SJ * 3 * ROW4;
     constexpr int NLD = (STAGE4 + 511) / 512;
     static_assert(NLD <= 4, "a stage is at most four rounds of 512 pieces");
@@ -804,7 +801,8 @@ struct thfhe_ctx {
     int32_t *d_ksk = nullptr; // padded rows
     int ks_w = 0;             // words per lane of a padded KSK row
     long ks_multi_min_gates = 1024;  // batches of at least this many gates use sk_keyswitch_multi_kernel (rows shared by the gates of a workgroup)
-    bool ks_staged = true;           // ... or, where its shape allows, sk_keyswitch_staged_kernel (rows staged in LDS, the digit selects an address)
+    long ks_staged_min_gates = 192;  // (measured: 128 gates 0.146 ms one gate per workgroup / 0.184 staged, 256 gates 0.381 / 0.201)
+    // ... and, where its shape allows, batches from this size on sk_keyswitch_staged_kernel (rows staged in LDS, the digit selects an address)
     int coop_max_jobs = 768;    // remainders (batch mod 2048) up to this many rotations use the cooperative (latency) kernel
     int ring4_max_jobs = 1024;  // ... above it and up to this many, the four-wave ring kernel (launch_br)
     cplx *d_tw = nullptr;
@@ -936,23 +934,32 @@ int enqueue_rotations(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1
 }
 
 int enqueue_keyswitch(thfhe_ctx *c, const int32_t *d_u, int32_t *d_out, size_t gates, int rot_per_gate, bool timed) {
+    const bool staged_shape = c->p.ks_basebit == 2 && (c->ks_w == 8 || c->ks_w == 10) && c->p.ks_t <= 8 && c->p.ks_t % 4 == 0;
+    if (staged_shape && (long)gates >= c->ks_staged_min_gates) {
+        // throughput variant: rows staged in LDS for 32 gates, the digit selects an address (sk_keyswitch_staged_kernel).  The coordinates are cut
+        // into 16 ranges (8 from 2 048 gates on: measured) whose partial sums meet in the zeroed output: 1 024 workgroups at 4 096 gates, 512 at 1 024.
+        // Measured on MI355X, n = 630: 4 096 gates 1.01 ms (one gate per workgroup 2.57, branch-selected rows 1.69), 1 024 gates 0.34 (0.58),
+        // 512 gates 0.24 (0.43), 256 gates 0.20 (0.38).
+        KSArgs k{c->d_ksk, d_u, d_out, (long)gates, rot_per_gate, c->p.n, c->p.ks_t, 2, gates >= 2048 ? 8 : 16};
+        THFHE_HIP(hipMemsetAsync(d_out, 0, gates * (size_t)(c->p.n + 1) * sizeof(int32_t), c->stream));
+        const dim3 sgrid((unsigned)((gates + 31) / 32), (unsigned)k.nsplit), sblock(512);
+        if (c->ks_w == 8) hipLaunchKernelGGL((sk_keyswitch_staged_kernel<8>), sgrid, sblock, 0, c->stream, k);
+        else hipLaunchKernelGGL((sk_keyswitch_staged_kernel<10>), sgrid, sblock, 0, c->stream, k);
+        if (timed && c->profiling) {
+            THFHE_HIP(hipEventRecord(c->ev[3], c->stream));
+            c->ev_valid = true;
+        }
+        THFHE_HIP(hipGetLastError());
+        return THFHE_OK;
+    }
     if (c->p.ks_basebit == 2 && (long)gates >= c->ks_multi_min_gates && (c->ks_w == 8 || c->ks_w == 10 || c->ks_w == 18)) {
-        // throughput variant: the gates of a workgroup share every row load; the coordinate range is cut in four so that 2048+ workgroups
-        // keep ~12 waves per CU in flight (measured on MI355X, 4096 gates, n = 630: 1.75 ms against 2.57 ms for one gate per workgroup;
-        // G = 16 or row double-buffering bring nothing more -- the loop is bound by its uniform-branch row selection, not by L2 any more)
+        // the rows of an (i, j) loaded once into registers for the gates of a workgroup, selected per gate by wave-uniform branches: the shapes the
+        // staged kernel does not take (n = 1024: W = 18; t not a multiple of 4).  The coordinate range is cut in four so that 2048+ workgroups keep
+        // ~12 waves per CU in flight.
         constexpr int kSplit = 4;
         KSArgs k{c->d_ksk, d_u, d_out, (long)gates, rot_per_gate, c->p.n, c->p.ks_t, 2, kSplit};
         THFHE_HIP(hipMemsetAsync(d_out, 0, gates * (size_t)(c->p.n + 1) * sizeof(int32_t), c->stream));
         const dim3 block(256);
-        if (c->ks_staged && (c->ks_w == 8 || c->ks_w == 10) && c->p.ks_t <= 8 && c->p.ks_t % 4 == 0) {
-#ifndef THFHE_KS_SPLIT
-#define THFHE_KS_SPLIT 16
-#endif
-            k.nsplit = THFHE_KS_SPLIT;   // 16 coordinate ranges: 2 048 workgroups at 4 096 gates, 512 at 1 024
-            const dim3 sgrid((unsigned)((gates + 31) / 32), THFHE_KS_SPLIT), sblock(512);
-            if (c->ks_w == 8) hipLaunchKernelGGL((sk_keyswitch_staged_kernel<8>), sgrid, sblock, 0, c->stream, k);
-            else hipLaunchKernelGGL((sk_keyswitch_staged_kernel<10>), sgrid, sblock, 0, c->stream, k);
-        } else
         if (c->ks_w == 8) hipLaunchKernelGGL((sk_keyswitch_multi_kernel<2, 0, 8>), dim3((unsigned)((gates + 7) / 8), kSplit), block, 0, c->stream, k);
         else if (c->ks_w == 10) hipLaunchKernelGGL((sk_keyswitch_multi_kernel<2, 1, 8>), dim3((unsigned)((gates + 7) / 8), kSplit), block, 0, c->stream, k);
         else hipLaunchKernelGGL((sk_keyswitch_multi_kernel<4, 1, 4>), dim3((unsigned)((gates + 3) / 4), kSplit), block, 0, c->stream, k);
