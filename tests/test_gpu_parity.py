@@ -180,6 +180,50 @@ def test_full_batch_4096_properties(O, sk128, gpu128):
         d.free()
 
 
+def _check_keyswitch(O, ck, orc, p, batch, seed):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(-2**31, 2**31, (batch, p.N + 1), dtype=np.int64).astype(np.int32)
+    u[0, :] = 0                      # every digit zero but the rounding offset's carry
+    u[min(1, batch - 1), :] = -1     # all digits 3
+    u[min(2, batch - 1), :] = 2**31 - 1
+    got = ck.keyswitch(u)
+    rows = sorted(set(list(range(min(batch, 40))) + list(range(max(0, batch - 40), batch)) + list(range(0, batch, 61))))
+    for g in rows:
+        assert np.array_equal(got[g], orc.keyswitch(u[g])), (batch, g)
+
+
+def test_every_keyswitch_kernel_bit_exact(O, sk128, gpu128):
+    """keyswitch (J/keyswitch.jl:45-80) through all three kernels: one gate per workgroup (< 192 gates), rows staged in LDS for 32 gates with the
+    digit selecting an address (from 192 gates on; 16 coordinate ranges, 8 from 2 048 gates on), also with a ragged last workgroup, and the
+    two-rotation input of the MUX epilogue (J/gates.jl:172-176) at a staged batch size."""
+    import thfhe
+    p, K, orc = sk128
+    for batch, seed in ((1, 1), (191, 2), (192, 3), (223, 4), (1000, 5), (2051, 6)):
+        _check_keyswitch(O, gpu128, orc, p, batch, seed)
+    B = 200
+    rng = np.random.default_rng(7)
+    bits = rng.integers(0, 2, (3, B))
+    cx, cy, cz = (enc(O, K, bits[q], 300 + q) for q in range(3))
+    got = thfhe.gate_mux(gpu128, cx, cy, cz)
+    assert np.array_equal(got, orc.gates(O.MUX, cx, cy, cz))
+    assert np.array_equal(K.decrypt_bits(got), np.where(bits[0] == 1, bits[1], bits[2]).astype(bool))
+
+
+@pytest.mark.parametrize("name,kw", [("SK-80", {}), ("SK-128", dict(ks_t=4)), ("SK-128", dict(ks_t=6)), ("SK-lib", {})])
+def test_keyswitch_shapes(O, name, kw):
+    """the staged kernel's other row length (n = 500: 8 words per lane), a key-switch depth of 4, and the shapes it hands to the other kernels
+    (t = 6: not a multiple of 4; n = 1024: 18 words per lane)"""
+    import thfhe
+    p = O.make_params(name, **kw)
+    s = O.SIGMAS[name]
+    K = O.SKKeys(p, 83, s["bk"], s["ks"])
+    orc = O.Oracle(p, K.bk, K.ksk)
+    ck = thfhe.CloudKey(thfhe.make_params(name, **kw), K.bk, K.ksk, device=0)
+    for batch, seed in ((37, 11), (230, 12), (1030, 13)):
+        _check_keyswitch(O, ck, orc, p, batch, seed)
+    ck.close()
+
+
 @pytest.mark.parametrize("name", ["SK-80", "SK-lib"])
 def test_other_parameter_sets(O, name):
     # J/api.jl:76-91 (l = 2, Bgbit = 10, n = 500) and src/libthfhe.cpp:316-338 (n = 1024)
