@@ -58,6 +58,14 @@ def test_ccs_2party_full_size_like_runtests(O):
     dev = np.abs(np.abs(K.phases(out) / 2.0**32) - 0.125)
     assert dev.max() < 0.125 and dev.mean() < 0.04     # the 2-party CCS set is noisy by design (about 0.03 rms after one bootstrap)
     assert np.array_equal(out[:2], orc.gates(O.NAND, c1[:2], c2[:2]))
+    # 200 gates: the key switch (ks 8/2, one mask per party) goes through the staged kernel; a ragged last workgroup
+    B2 = 200
+    m1, m2 = rng.integers(0, 2, B2), rng.integers(0, 2, B2)
+    c1, c2 = K.encrypt_bits(m1, s["lwe"], 43), K.encrypt_bits(m2, s["lwe"], 44)
+    out = thfhe.mk_gate_nand(ck, c1, c2)
+    assert np.array_equal(K.decrypt_bits(out), ~(m1.astype(bool) & m2.astype(bool)))
+    pick = [0, 1, 31, 32, 191, 192, 199]
+    assert np.array_equal(out[pick], orc.gates(O.NAND, c1[pick], c2[pick]))
     assert np.array_equal(out, thfhe.mk_gate_nand(ck, c1, c2))       # deterministic
     print(f"CCS 2-party NAND: {B} gates in {dt * 1e3:.1f} ms")
     ck.close()

@@ -78,6 +78,19 @@ def test_kms2_truth_table_larger_n(O):
     ck.close()
 
 
+def test_kms2_keyswitch_full_n_both_kernels(O):
+    # mk_keyswitch (mk_internals.jl:714-728) at the reference's n = 560 (640-word rows): 100 samples one workgroup per (sample, party), 260 through
+    # the staged kernel; P N + 1 = 4097-word extracted samples with one mask per party
+    p, K, orc, ck = setup(O, "KMS2", 560, seed=10)
+    rng = np.random.default_rng(14)
+    for count in (100, 260):
+        u = rng.integers(-2**31, 2**31, (count, p.parties * p.N + 1), dtype=np.int64).astype(np.int32)
+        got = ck.keyswitch(u)
+        for g in list(range(8)) + list(range(count - 40, count)):
+            assert np.array_equal(got[g], orc.keyswitch(u[g])), (count, g)
+    ck.close()
+
+
 @pytest.mark.parametrize("name,n,parties", [("KMS16", 2, 16), ("KMS32", 2, 32)])
 def test_kms_16_and_32_party_sets_at_the_real_party_count(O, name, n, parties):
     # mktfhe_parameters_16party_new / _32party_new (mk_api.jl:194-202, 225-233) with ALL 16 / 32 parties (17 / 33 accumulator polynomials, the

@@ -16,6 +16,35 @@ def mk2gpu(O):
     ck.close()
 
 
+def check_mk_keyswitch(ck, orc, p, counts, seed):
+    """mk_keyswitch_3gen (J/mk_internals.jl:730-744) of random extracted samples through thfhe_mk_keyswitch_dev: below 192 samples one workgroup
+    per (sample, party), from 192 on the staged kernel (rows in LDS, the digit selects an address); sampled rows against the oracle."""
+    import ctypes as C
+    import torch
+    import thfhe
+    rng = np.random.default_rng(seed)
+    for count in counts:
+        u = rng.integers(-2**31, 2**31, (count, p.N + 1), dtype=np.int64).astype(np.int32)
+        u[0, :] = 0
+        u[count - 1, :] = -1
+        ut = torch.from_numpy(u).cuda()
+        out = torch.empty((count, p.parties * p.n + 1), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        rc = thfhe.lib().thfhe_mk_keyswitch_dev(ck.h, C.c_void_p(ut.data_ptr()), C.c_void_p(out.data_ptr()), count)
+        assert rc == 0
+        ck.sync()
+        got = out.cpu().numpy()
+        rows = sorted(set(list(range(min(count, 12))) + list(range(max(0, count - 36), count)) + list(range(0, count, 97))))
+        for g in rows:
+            assert np.array_equal(got[g], orc.keyswitch(u[g])), (count, g)
+
+
+def test_mk2_keyswitch_kernels_bit_exact(O, mk2gpu):
+    # ks 3/3: seven rows per (i, j), three levels -- stages straddle coordinates; ragged last workgroups
+    p, K, orc, ck = mk2gpu
+    check_mk_keyswitch(ck, orc, p, (5, 191, 192, 333, 1025), 21)
+
+
 def test_mk2_gates_bit_exact(O, mk2gpu):
     # mk_gate_{nand,or,and,xor,3and,mux,not}_3gen, J/3gen_mk_gates.jl:8-150
     import thfhe
@@ -82,6 +111,7 @@ def test_mk4_bit_exact(O):
     got = ck.gates(thfhe.NAND, ca, cb)
     assert np.array_equal(got, orc.gates(O.NAND, ca, cb))
     assert np.array_equal(K.decrypt_bits(got), ~(a.astype(bool) & b.astype(bool)))
+    check_mk_keyswitch(ck, orc, p, (100, 230), 22)   # ks 5/2: three rows per (i, j), five levels
     ck.close()
 
 
@@ -265,6 +295,7 @@ def test_mk4_n2048_full_size(O):
     ck.set_pair_threshold(0)                                     # the same 96 gates two per workgroup (mk_blind_rotate_pair2k_kernel) at full size
     assert ck.rotation_kernel_name(B) == "mk_blind_rotate_pair2k_kernel<3>"
     assert np.array_equal(got, ck.gates(thfhe.NAND, ca, cb))
+    check_mk_keyswitch(ck, orc, p, (200,), 23)                   # N = 2048 coordinates per party through the staged key switch
     ck.close()
 
 

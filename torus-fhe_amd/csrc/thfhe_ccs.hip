@@ -391,7 +391,7 @@ int ccs_run(thfhe_ccs_ctx *c, MKLin L, const int32_t *in0, const int32_t *in1, i
     MKKSArgs k{c->d_ksk, c->d_u, c->d_out, (long)count, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words, 1024, c->p.parties * 1024 + 1, 1024};
     const int nsplit = count * c->p.parties <= 64 ? 16 : (count * c->p.parties <= 256 ? 4 : 1);
     THFHE_HIP(hipMemsetAsync(c->d_out, 0, bytes, c->stream));
-    hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)count, (unsigned)c->p.parties, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
+    mk_launch_keyswitch(k, nsplit, c->stream);
     THFHE_HIP(hipGetLastError());
     THFHE_HIP(hipMemcpyAsync(out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     THFHE_HIP(hipStreamSynchronize(c->stream));

@@ -326,7 +326,7 @@ int thfhe_kms_keyswitch(thfhe_kms_ctx *c, const int32_t *u, int32_t *out, size_t
     THFHE_HIP(hipMemsetAsync(c->d_buf[2], 0, out_words * sizeof(int32_t), c->stream));
     MKKSArgs k{c->d_ksk, (const int32_t *)c->d_buf[1], (int32_t *)c->d_buf[2], (long)count, n, c->p.ks_t, c->p.ks_basebit, P, c->row_words, N, P * N + 1, N};
     const int nsplit = count <= 64 ? 8 : 2;
-    hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)count, (unsigned)P, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
+    mk_launch_keyswitch(k, nsplit, c->stream);
     THFHE_HIP(hipGetLastError());
     THFHE_HIP(hipMemcpyAsync(out, c->d_buf[2], out_words * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     THFHE_HIP(hipStreamSynchronize(c->stream));
@@ -556,7 +556,7 @@ int kms_bootstrap_body(thfhe_kms_ctx *c, KmsTables &tabs, int32_t cb, int32_t cx
         MKKSArgs k{c->d_ksk, (const int32_t *)c->d_w[K::W_U], (int32_t *)c->d_w[K::W_OUT], (long)G, n, c->p.ks_t, c->p.ks_basebit, P, c->row_words, (int)N,
                    (int)uw, (int)N};
         const int nsplit = G <= 64 ? 8 : 2;
-        hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)G, (unsigned)P, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
+        mk_launch_keyswitch(k, nsplit, c->stream);
         THFHE_HIP(hipGetLastError());
         THFHE_HIP(hipMemcpyAsync(out, c->d_w[K::W_OUT], G * words * 4, hipMemcpyDeviceToHost, c->stream));
     }
@@ -719,7 +719,7 @@ int thfhe_kms_finish_dev(thfhe_kms_ctx *c, int op, const int32_t *d_x, const int
         THFHE_HIP(hipMemsetAsync(d_out, 0, G * words * 4, c->stream));
         MKKSArgs k{c->d_ksk, (const int32_t *)c->d_w[K::W_U], d_out, (long)G, n, c->p.ks_t, c->p.ks_basebit, P, c->row_words, (int)N, (int)uw, (int)N};
         const int nsplit = G <= 64 ? 8 : 2;
-        hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)G, (unsigned)P, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
+        mk_launch_keyswitch(k, nsplit, c->stream);
         THFHE_HIP(hipGetLastError());
         return kms_finish(c);
     };

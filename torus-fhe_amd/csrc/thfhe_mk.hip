@@ -996,7 +996,7 @@ int mk_enqueue_bootstraps(thfhe_mk_ctx *c, const int32_t *d0, const int32_t *d1,
     MKKSArgs k{c->d_ksk, c->d_u, d_dst, (long)jobs, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words, c->p.N, c->p.N + 1, 0};
     const int nsplit = jobs * c->p.parties <= 64 ? 16 : (jobs * c->p.parties <= 256 ? 4 : (c->p.N > 2048 ? 2 : 1));  // fill the chip at small batch sizes; a block holds <= 2048 mask words
     THFHE_HIP(hipMemsetAsync(d_dst, 0, jobs * ((size_t)c->words + 1) * sizeof(int32_t), c->stream));
-    hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)jobs, (unsigned)c->p.parties, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
+    mk_launch_keyswitch(k, nsplit, c->stream);
     if (c->profiling) {
         THFHE_HIP(hipEventRecord(c->ev[3], c->stream));
         c->ev_valid = true;
@@ -1570,7 +1570,7 @@ int thfhe_mk_keyswitch_dev(thfhe_mk_ctx *c, const int32_t *d_u, int32_t *d_out, 
     MKKSArgs k{c->d_ksk, d_u, d_out, (long)count, c->p.n, c->p.ks_t, c->p.ks_basebit, c->p.parties, c->row_words, c->p.N, c->p.N + 1, 0};
     const int nsplit = count * c->p.parties <= 64 ? 16 : (count * c->p.parties <= 256 ? 4 : (c->p.N > 2048 ? 2 : 1));
     THFHE_HIP(hipMemsetAsync(d_out, 0, count * ((size_t)c->words + 1) * sizeof(int32_t), c->stream));
-    hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)count, (unsigned)c->p.parties, (unsigned)nsplit), dim3(256), 0, c->stream, k, nsplit);
+    mk_launch_keyswitch(k, nsplit, c->stream);
     THFHE_HIP(hipGetLastError());
     return THFHE_OK;
 }

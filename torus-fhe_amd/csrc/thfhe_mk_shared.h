@@ -129,6 +129,163 @@ __global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a, int nspli
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// key switch, staged variant (from 192 samples on; row of 512 or 640 words, ks_basebit 2 or 3, t * ks_basebit <= 16): the single-key kernel of
+// thfhe_sk.hip (sk_keyswitch_staged_kernel) per party.  A workgroup of eight waves takes 32 samples, one party and 128 (basebit 2) or 64
+// (basebit 3) coordinates; it copies the rows KS[p][i][j][1 .. base-1] of four (two) consecutive (i, j) at a time into LDS -- contiguous in global
+// memory, double buffered through registers -- and every lane reads its part of the row its sample's digit names (digit 0: a row of zeros)
+// with ds_read_b128: the digit selects an address, not a branch, and base-1 rows per (i, j) leave L2 once for 32 samples instead of 0.75 .. 0.88
+// rows per sample.  A wave takes four samples, one per 16-lane group of the LDS hardware, so a group reads 16 consecutive pieces of ONE row
+// = every bank once.  Partial sums of the coordinate ranges and the parties' parts of b meet in the zeroed output with integer atomics.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mk_ks_sub(uint32_t &r, uint32_t x) { asm("v_sub_u32 %0, %0, %1" : "+v"(r) : "v"(x)); }   // in place, never re-associated
+template <int W, int R>   // W: 16-byte pieces per lane (row_words = 64 W); R = 2^basebit - 1 rows per (i, j)
+__global__ __launch_bounds__(512) void mk_keyswitch_staged_kernel(MKKSArgs a) {
+    constexpr int ROW4 = 16 * W, Q = W, GW = 32;
+    constexpr int SJ = R == 3 ? 4 : 2;           // (i, j) pairs per stage: 12 / 14 rows
+    constexpr int SPAN = R == 3 ? 128 : 64;      // coordinates per workgroup
+    constexpr int STAGE4 = SJ * R * ROW4;
+    constexpr int NLD = (STAGE4 + 511) / 512;
+    constexpr int KS_CHUNK = 3;
+    static_assert(NLD <= 5, "a stage is at most five rounds of 512 pieces");
+    __shared__ uint4 sL[ROW4 + 2 * STAGE4];      // [row of zeros][stage 0][stage 1]
+    __shared__ uint16_t sDig[GW][SPAN];          // top 16 bits of u + offset: all t digits of a coordinate
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int q5 = lane & 31;
+    const int gl = 2 * (lane >> 5) + (int)((0xF00F0FF0u >> q5) & 1u);   // the lane's ds_read_b128 group = its sample within the wave
+    const int c = q5 < 4 ? q5 : q5 < 12 ? q5 - 4 : q5 < 20 ? q5 - 8 : q5 < 28 ? q5 - 12 : q5 - 16;   // position in the group: 0 .. 15
+    const long g0 = (long)blockIdx.x * GW;
+    const int p = blockIdx.y;
+    const int first = (int)blockIdx.z * SPAN;
+    const uint32_t prec_offset = 1u << (32 - (1 + a.basebit * a.t));
+    for (int q = tid; q < GW * SPAN; q += 512) {
+        const int g = q / SPAN, ii = q % SPAN;
+        uint32_t v = 0;
+        if (g0 + g < a.gates) v = (uint32_t)a.u[(size_t)(g0 + g) * a.u_rec + (size_t)p * a.u_pstride + first + ii] + prec_offset;
+        sDig[g][ii] = (uint16_t)(v >> 16);  // absent samples: all digits zero
+    }
+    for (int q = tid; q < ROW4; q += 512) sL[q] = uint4{0u, 0u, 0u, 0u};
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.ksk) + ((size_t)p * a.N + first) * a.t * R * ROW4;
+    const int NS = SPAN * a.t / SJ;
+    uint4 pre0, pre1 = uint4{0u, 0u, 0u, 0u}, pre2 = pre1, pre3 = pre1, pre4 = pre1;
+    const bool last_ok = 512 * NLD <= STAGE4 || tid + 512 * (NLD - 1) < STAGE4;
+    const int last_idx = last_ok ? tid + 512 * (NLD - 1) : STAGE4 - 1;
+#define MK_KS_GLOAD(st)                                           \
+    {                                                             \
+        const uint4 *p_ = src + (size_t)(st) * STAGE4;            \
+        pre0 = p_[NLD == 1 ? last_idx : tid];                     \
+        if (NLD > 1) pre1 = p_[NLD == 2 ? last_idx : tid + 512];  \
+        if (NLD > 2) pre2 = p_[NLD == 3 ? last_idx : tid + 1024]; \
+        if (NLD > 3) pre3 = p_[NLD == 4 ? last_idx : tid + 1536]; \
+        if (NLD > 4) pre4 = p_[last_idx];                         \
+    }
+#define MK_KS_LSTORE(buf)                                         \
+    {                                                             \
+        uint4 *d_ = sL + ROW4 + (buf) * STAGE4 + tid;             \
+        if (NLD > 1 || last_ok) d_[0] = pre0;                     \
+        if (NLD > 2 || (NLD == 2 && last_ok)) d_[512] = pre1;     \
+        if (NLD > 3 || (NLD == 3 && last_ok)) d_[1024] = pre2;    \
+        if (NLD > 4 || (NLD == 4 && last_ok)) d_[1536] = pre3;    \
+        if (NLD == 5 && last_ok) d_[2048] = pre4;                 \
+    }
+    MK_KS_GLOAD(0)
+    MK_KS_LSTORE(0)
+    __syncthreads();
+    uint4 acc[Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) acc[k] = uint4{0u, 0u, 0u, 0u};
+    const uint16_t *dig = sDig[wave * 4 + gl];
+    const uint32_t dmask = (uint32_t)R;
+    int ii0 = 0, j0 = 0;   // coordinate and level of the stage's first pair
+    for (int st = 0; st < NS; st++) {
+        if (st + 1 < NS) {
+            MK_KS_GLOAD(st + 1)
+        }
+        const uint4 *row[SJ];
+#pragma unroll
+        for (int pp = 0; pp < SJ; pp++) {
+            int ii = ii0, j = j0 + pp;
+            while (j >= a.t) j -= a.t, ii++;
+            const uint32_t d = ((uint32_t)dig[ii] >> (16 - (j + 1) * a.basebit)) & dmask;
+            row[pp] = sL + (d ? ROW4 + (st & 1) * STAGE4 + (pp * R + (int)d - 1) * ROW4 : 0) + c;
+        }
+        j0 += SJ;
+        while (j0 >= a.t) j0 -= a.t, ii0++;
+        constexpr int NCH = (Q + KS_CHUNK - 1) / KS_CHUNK;
+        uint4 x[2][KS_CHUNK];
+        auto reads = [&](int ch) {   // ch < SJ * NCH, compile-time after unrolling
+            const uint4 *r = row[ch / NCH];
+            const int k0 = (ch % NCH) * KS_CHUNK;
+#pragma unroll
+            for (int k = 0; k < KS_CHUNK; k++)
+                if (k0 + k < Q) x[ch & 1][k] = r[16 * (k0 + k)];
+        };
+        reads(0);
+#pragma unroll
+        for (int ch = 0; ch < SJ * NCH; ch++) {
+            if (ch + 1 < SJ * NCH) reads(ch + 1);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const int k0 = (ch % NCH) * KS_CHUNK;
+#pragma unroll
+            for (int k = 0; k < KS_CHUNK; k++)
+                if (k0 + k < Q) {
+                    uint4 &t = acc[k0 + k];
+                    const uint4 v = x[ch & 1][k];
+                    mk_ks_sub(t.x, v.x), mk_ks_sub(t.y, v.y), mk_ks_sub(t.z, v.z), mk_ks_sub(t.w, v.w);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (st + 1 < NS) {
+            MK_KS_LSTORE((st + 1) & 1)
+        }
+        __syncthreads();
+    }
+#undef MK_KS_GLOAD
+#undef MK_KS_LSTORE
+    const long g = g0 + wave * 4 + gl;
+    if (g < a.gates) {
+        unsigned int *out = reinterpret_cast<unsigned int *>(a.out) + (size_t)g * ((size_t)a.parties * a.n + 1);
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            const uint32_t v4[4] = {acc[k].x, acc[k].y, acc[k].z, acc[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int col = 4 * (c + 16 * k) + e;
+                uint32_t v = v4[e];
+                if (col < a.n) {
+                    atomicAdd(out + (size_t)p * a.n + col, v);
+                } else if (col == a.n) {
+                    if (p == 0 && blockIdx.z == 0) v += (uint32_t)a.u[(size_t)g * a.u_rec + a.u_rec - 1];  // b = b' + sum over parties of the parts' b
+                    atomicAdd(out + (size_t)a.parties * a.n, v);
+                }
+            }
+        }
+    }
+}
+
+// the key switch of `k.gates` extracted samples into the ZEROED k.out: staged kernel where its shape allows, else one workgroup per (sample, party, range)
+inline bool mk_ks_staged_shape(const MKKSArgs &k) {
+    const bool w = k.row_words == 512 || k.row_words == 640;
+    const bool base = k.basebit == 2 || k.basebit == 3;
+    return w && base && k.t >= 3 && k.t * k.basebit <= 16 && k.N % (k.basebit == 2 ? 128 : 64) == 0 && k.n < k.row_words;
+}
+inline void mk_launch_keyswitch(const MKKSArgs &k, int nsplit_plain, hipStream_t stream, long staged_min = 192) {
+    if (k.gates >= staged_min && mk_ks_staged_shape(k)) {
+        const int span = k.basebit == 2 ? 128 : 64;
+        const dim3 grid((unsigned)((k.gates + 31) / 32), (unsigned)k.parties, (unsigned)(k.N / span)), block(512);
+        if (k.row_words == 512) {
+            if (k.basebit == 2) hipLaunchKernelGGL((mk_keyswitch_staged_kernel<8, 3>), grid, block, 0, stream, k);
+            else hipLaunchKernelGGL((mk_keyswitch_staged_kernel<8, 7>), grid, block, 0, stream, k);
+        } else {
+            if (k.basebit == 2) hipLaunchKernelGGL((mk_keyswitch_staged_kernel<10, 3>), grid, block, 0, stream, k);
+            else hipLaunchKernelGGL((mk_keyswitch_staged_kernel<10, 7>), grid, block, 0, stream, k);
+        }
+        return;
+    }
+    hipLaunchKernelGGL(mk_keyswitch_kernel, dim3((unsigned)k.gates, (unsigned)k.parties, (unsigned)nsplit_plain), dim3(256), 0, stream, k, nsplit_plain);
+}
+
 }  // namespace
 
 #endif  // THFHE_MK_SHARED_H
