@@ -19,21 +19,18 @@ def mk2gpu(O):
 def check_mk_keyswitch(ck, orc, p, counts, seed):
     """mk_keyswitch_3gen (J/mk_internals.jl:730-744) of random extracted samples through thfhe_mk_keyswitch_dev: below 192 samples one workgroup
     per (sample, party), from 192 on the staged kernel (rows in LDS, the digit selects an address); sampled rows against the oracle."""
-    import ctypes as C
-    import torch
     import thfhe
     rng = np.random.default_rng(seed)
     for count in counts:
         u = rng.integers(-2**31, 2**31, (count, p.N + 1), dtype=np.int64).astype(np.int32)
         u[0, :] = 0
         u[count - 1, :] = -1
-        ut = torch.from_numpy(u).cuda()
-        out = torch.empty((count, p.parties * p.n + 1), dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
-        rc = thfhe.lib().thfhe_mk_keyswitch_dev(ck.h, C.c_void_p(ut.data_ptr()), C.c_void_p(out.data_ptr()), count)
-        assert rc == 0
+        du = thfhe.DeviceBuffer(ck, u.nbytes).upload(u)
+        do = thfhe.DeviceBuffer(ck, count * (p.parties * p.n + 1) * 4)
+        assert thfhe.lib().thfhe_mk_keyswitch_dev(ck.h, du.ptr, do.ptr, count) == 0
         ck.sync()
-        got = out.cpu().numpy()
+        got = do.download((count, p.parties * p.n + 1))
+        du.free(); do.free()
         rows = sorted(set(list(range(min(count, 12))) + list(range(max(0, count - 36), count)) + list(range(0, count, 97))))
         for g in rows:
             assert np.array_equal(got[g], orc.keyswitch(u[g])), (count, g)
