@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void sk_keyswitch_multi_kernel(KSArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// key switch, staged variant (ks_basebit == 2, t a multiple of 4 and <= 8, W <= 10, >= 1 024 gates).  The kernel above selects a row per gate with
+// key switch, staged variant (ks_basebit == 2, t <= 8 and a multiple of the stage depth, rows of 512 / 640 / 1152 words, >= 192 gates).  The kernel above selects a row per gate with
 // wave-uniform branches; the compiler turns that chain into flag-guarded blocks with subtract-into-a-copy + moves, and the loop runs at a
 // quarter of its subtraction rate.  Here the digit selects an ADDRESS: a workgroup of eight waves copies the rows KS[i][j][1..3] of four
 // (i, j) at a time into LDS (twelve contiguous rows in global memory; double buffered through registers), and a lane reads its part of the
@@ -652,11 +652,11 @@ __global__ __launch_bounds__(256) void sk_keyswitch_multi_kernel(KSArgs a) {
 // coordinate ranges meet in the zeroed output with integer atomics (adds commute: bit-exact).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ks_sub(uint32_t &r, uint32_t x) { asm("v_sub_u32 %0, %0, %1" : "+v"(r) : "v"(x)); }   // in place, never re-associated
-template <int W>
+template <int W, int SJ>   // W: 16-byte pieces per lane (row of 64 W words); SJ: (i, j) pairs per stage (4; 2 for the long rows of n = 1024)
 __global__ __launch_bounds__(512) void sk_keyswitch_staged_kernel(KSArgs a) {
     constexpr int ROW4 = 16 * W;             // 16-byte pieces of a padded row
     constexpr int Q = W;                     // pieces per lane: sixteen lanes share a row
-    constexpr int GW = 32, SJ = 4;           // gates per workgroup, (i, j) pairs per stage
+    constexpr int GW = 32;                   // gates per workgroup
     constexpr int KS_CHUNK = 3;              // reads in flight behind the ones being subtracted (measured: 3 <= 5 < 10; SJ = 2 loses 4 %)
     constexpr int STAGE4 = SJ * 3 * ROW4;
     constexpr int NLD = (STAGE4 + 511) / 512;
@@ -934,7 +934,8 @@ int enqueue_rotations(thfhe_ctx *c, int op, const int32_t *d0, const int32_t *d1
 }
 
 int enqueue_keyswitch(thfhe_ctx *c, const int32_t *d_u, int32_t *d_out, size_t gates, int rot_per_gate, bool timed) {
-    const bool staged_shape = c->p.ks_basebit == 2 && (c->ks_w == 8 || c->ks_w == 10) && c->p.ks_t <= 8 && c->p.ks_t % 4 == 0;
+    const bool staged_shape = c->p.ks_basebit == 2 && c->p.ks_t <= 8 &&
+                              (((c->ks_w == 8 || c->ks_w == 10) && c->p.ks_t % 4 == 0) || (c->ks_w == 18 && c->p.ks_t % 2 == 0));
     if (staged_shape && (long)gates >= c->ks_staged_min_gates) {
         // throughput variant: rows staged in LDS for 32 gates, the digit selects an address (sk_keyswitch_staged_kernel).  The coordinates are cut
         // into 16 ranges (8 from 2 048 gates on: measured) whose partial sums meet in the zeroed output: 1 024 workgroups at 4 096 gates, 512 at 1 024.
@@ -943,8 +944,9 @@ int enqueue_keyswitch(thfhe_ctx *c, const int32_t *d_u, int32_t *d_out, size_t g
         KSArgs k{c->d_ksk, d_u, d_out, (long)gates, rot_per_gate, c->p.n, c->p.ks_t, 2, gates >= 2048 ? 8 : 16};
         THFHE_HIP(hipMemsetAsync(d_out, 0, gates * (size_t)(c->p.n + 1) * sizeof(int32_t), c->stream));
         const dim3 sgrid((unsigned)((gates + 31) / 32), (unsigned)k.nsplit), sblock(512);
-        if (c->ks_w == 8) hipLaunchKernelGGL((sk_keyswitch_staged_kernel<8>), sgrid, sblock, 0, c->stream, k);
-        else hipLaunchKernelGGL((sk_keyswitch_staged_kernel<10>), sgrid, sblock, 0, c->stream, k);
+        if (c->ks_w == 8) hipLaunchKernelGGL((sk_keyswitch_staged_kernel<8, 4>), sgrid, sblock, 0, c->stream, k);
+        else if (c->ks_w == 10) hipLaunchKernelGGL((sk_keyswitch_staged_kernel<10, 4>), sgrid, sblock, 0, c->stream, k);
+        else hipLaunchKernelGGL((sk_keyswitch_staged_kernel<18, 2>), sgrid, sblock, 0, c->stream, k);
         if (timed && c->profiling) {
             THFHE_HIP(hipEventRecord(c->ev[3], c->stream));
             c->ev_valid = true;
@@ -954,7 +956,7 @@ int enqueue_keyswitch(thfhe_ctx *c, const int32_t *d_u, int32_t *d_out, size_t g
     }
     if (c->p.ks_basebit == 2 && (long)gates >= c->ks_multi_min_gates && (c->ks_w == 8 || c->ks_w == 10 || c->ks_w == 18)) {
         // the rows of an (i, j) loaded once into registers for the gates of a workgroup, selected per gate by wave-uniform branches: the shapes the
-        // staged kernel does not take (n = 1024: W = 18; t not a multiple of 4).  The coordinate range is cut in four so that 2048+ workgroups keep
+        // staged kernel does not take (t not a multiple of its stage depth).  The coordinate range is cut in four so that 2048+ workgroups keep
         // ~12 waves per CU in flight.
         constexpr int kSplit = 4;
         KSArgs k{c->d_ksk, d_u, d_out, (long)gates, rot_per_gate, c->p.n, c->p.ks_t, 2, kSplit};
