@@ -42,6 +42,19 @@ def test_mk2_keyswitch_kernels_bit_exact(O, mk2gpu):
     check_mk_keyswitch(ck, orc, p, (5, 191, 192, 333, 1025), 21)
 
 
+@pytest.mark.parametrize("name", ["MK64", "MK256"])
+def test_mk_keyswitch_768_word_rows(O, name):
+    # n = 650 (ks 4/3: seven rows per (i, j), ONE (i, j) per stage) and n = 740 (ks 8/2, two per stage) at the sets' own LWE dimension, two parties
+    import thfhe
+    p = O.make_params(name, parties=2)
+    s = O.SIGMAS[name]
+    K = O.MKKeys(p, 79, s["bk"], s["ks"])
+    orc = O.MKOracle(p, K.bk, K.ksk)
+    ck = thfhe.MKCloudKey(thfhe.make_params(name, parties=2), K.bk, K.ksk, device=0)
+    check_mk_keyswitch(ck, orc, p, (64, 230), 24)
+    ck.close()
+
+
 def test_mk2_gates_bit_exact(O, mk2gpu):
     # mk_gate_{nand,or,and,xor,3and,mux,not}_3gen, J/3gen_mk_gates.jl:8-150
     import thfhe

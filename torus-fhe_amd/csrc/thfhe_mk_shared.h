@@ -130,19 +130,18 @@ __global__ __launch_bounds__(256) void mk_keyswitch_kernel(MKKSArgs a, int nspli
 }
 
 // ------------------------------------------------------------------------------------------------------
-// key switch, staged variant (from 192 samples on; row of 512 or 640 words, ks_basebit 2 or 3, t * ks_basebit <= 16): the single-key kernel of
+// key switch, staged variant (from 192 samples on; row of 512, 640 or 768 words, ks_basebit 2 or 3, t * ks_basebit <= 16): the single-key kernel of
 // thfhe_sk.hip (sk_keyswitch_staged_kernel) per party.  A workgroup of eight waves takes 32 samples, one party and 128 (basebit 2) or 64
-// (basebit 3) coordinates; it copies the rows KS[p][i][j][1 .. base-1] of four (two) consecutive (i, j) at a time into LDS -- contiguous in global
+// (basebit 3) coordinates; it copies the rows KS[p][i][j][1 .. base-1] of four (two; with 768-word rows two (one)) consecutive (i, j) at a time into LDS -- contiguous in global
 // memory, double buffered through registers -- and every lane reads its part of the row its sample's digit names (digit 0: a row of zeros)
 // with ds_read_b128: the digit selects an address, not a branch, and base-1 rows per (i, j) leave L2 once for 32 samples instead of 0.75 .. 0.88
 // rows per sample.  A wave takes four samples, one per 16-lane group of the LDS hardware, so a group reads 16 consecutive pieces of ONE row
 // = every bank once.  Partial sums of the coordinate ranges and the parties' parts of b meet in the zeroed output with integer atomics.
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void mk_ks_sub(uint32_t &r, uint32_t x) { asm("v_sub_u32 %0, %0, %1" : "+v"(r) : "v"(x)); }   // in place, never re-associated
-template <int W, int R>   // W: 16-byte pieces per lane (row_words = 64 W); R = 2^basebit - 1 rows per (i, j)
+template <int W, int R, int SJ>   // W: 16-byte pieces per lane (row_words = 64 W); R = 2^basebit - 1 rows per (i, j); SJ: (i, j) pairs per stage
 __global__ __launch_bounds__(512) void mk_keyswitch_staged_kernel(MKKSArgs a) {
     constexpr int ROW4 = 16 * W, Q = W, GW = 32;
-    constexpr int SJ = R == 3 ? 4 : 2;           // (i, j) pairs per stage: 12 / 14 rows
     constexpr int SPAN = R == 3 ? 128 : 64;      // coordinates per workgroup
     constexpr int STAGE4 = SJ * R * ROW4;
     constexpr int NLD = (STAGE4 + 511) / 512;
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(512) void mk_keyswitch_staged_kernel(MKKSArgs a) {
 
 // the key switch of `k.gates` extracted samples into the ZEROED k.out: staged kernel where its shape allows, else one workgroup per (sample, party, range)
 inline bool mk_ks_staged_shape(const MKKSArgs &k) {
-    const bool w = k.row_words == 512 || k.row_words == 640;
+    const bool w = k.row_words == 512 || k.row_words == 640 || k.row_words == 768;
     const bool base = k.basebit == 2 || k.basebit == 3;
     return w && base && k.t >= 3 && k.t * k.basebit <= 16 && k.N % (k.basebit == 2 ? 128 : 64) == 0 && k.n < k.row_words;
 }
@@ -274,12 +273,16 @@ inline void mk_launch_keyswitch(const MKKSArgs &k, int nsplit_plain, hipStream_t
     if (k.gates >= staged_min && mk_ks_staged_shape(k)) {
         const int span = k.basebit == 2 ? 128 : 64;
         const dim3 grid((unsigned)((k.gates + 31) / 32), (unsigned)k.parties, (unsigned)(k.N / span)), block(512);
+        // stage depth by LDS: two stages + the row of zeros + the digits stay under half a CU's LDS (two workgroups per CU)
         if (k.row_words == 512) {
-            if (k.basebit == 2) hipLaunchKernelGGL((mk_keyswitch_staged_kernel<8, 3>), grid, block, 0, stream, k);
-            else hipLaunchKernelGGL((mk_keyswitch_staged_kernel<8, 7>), grid, block, 0, stream, k);
+            if (k.basebit == 2) hipLaunchKernelGGL((mk_keyswitch_staged_kernel<8, 3, 4>), grid, block, 0, stream, k);
+            else hipLaunchKernelGGL((mk_keyswitch_staged_kernel<8, 7, 2>), grid, block, 0, stream, k);
+        } else if (k.row_words == 640) {
+            if (k.basebit == 2) hipLaunchKernelGGL((mk_keyswitch_staged_kernel<10, 3, 4>), grid, block, 0, stream, k);
+            else hipLaunchKernelGGL((mk_keyswitch_staged_kernel<10, 7, 2>), grid, block, 0, stream, k);
         } else {
-            if (k.basebit == 2) hipLaunchKernelGGL((mk_keyswitch_staged_kernel<10, 3>), grid, block, 0, stream, k);
-            else hipLaunchKernelGGL((mk_keyswitch_staged_kernel<10, 7>), grid, block, 0, stream, k);
+            if (k.basebit == 2) hipLaunchKernelGGL((mk_keyswitch_staged_kernel<12, 3, 2>), grid, block, 0, stream, k);
+            else hipLaunchKernelGGL((mk_keyswitch_staged_kernel<12, 7, 1>), grid, block, 0, stream, k);
         }
         return;
     }
