@@ -10,8 +10,11 @@
 //   mk_key_transform_kernel   TransformedBootstrapKeyPart_3gen (J/3gen_mk_internals.jl:45-56): int64 coefficient
 //                             polynomials -> four balanced 16-bit limbs -> FP64 spectra in streaming order
 //   mk_prologue_kernel        gate linear part + mod-switch of the (n, P) mask matrix and of b
-//   mk_blind_rotate_coop_kernel   one 512-thread workgroup per gate: the eight (output polynomial, limb) spectra on eight waves
-//   mk_keyswitch_kernel       P key switches of the extracted sample + the cross-party combine of b
+//   mk_blind_rotate_coop_kernel / _pair_kernel   one 512-thread workgroup per gate / per two gates: the eight (output polynomial, limb) spectra on
+//                             eight waves; _coop2k / _pair2k on the ring of degree 2048 (two twisted half transforms per polynomial);
+//                             thfhe_rot2k.h (any number of digit row parts, N = 2048) and thfhe_rot4k.h (N = 4096) for the large-party sets
+//   mk_keyswitch_kernel / mk_keyswitch_staged_kernel (thfhe_mk_shared.h)   P key switches of the extracted sample + the cross-party combine
+//                             of b: one workgroup per (sample, party, range), or from 192 samples on the rows staged in LDS for 32 samples
 #include <hip/hip_runtime.h>
 
 #include <type_traits>

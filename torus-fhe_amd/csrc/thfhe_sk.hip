@@ -8,7 +8,9 @@
 //   sk_blind_rotate_ring_kernel / sk_blind_rotate_coop_kernel   blind_rotate_and_extract (J/bootstrap.jl:38-65): accumulator in
 //                             LDS for all n CMuxes; throughput (8 gates per workgroup, key through an LDS-DMA ring) and latency
 //                             (one workgroup per gate) variants
-//   sk_keyswitch_kernel       keyswitch (J/keyswitch.jl:45-80) (+ the MUX combine of J/gates.jl:172-176)
+//   sk_keyswitch_kernel / sk_keyswitch_staged_kernel / sk_keyswitch_multi_kernel   keyswitch (J/keyswitch.jl:45-80) (+ the MUX combine of
+//                             J/gates.jl:172-176): one gate per workgroup (small batches); from 192 gates on the rows of a few (i, j) staged in
+//                             LDS for 32 gates, the digit selecting an address; rows in registers selected by branches for the remaining shapes
 //   sk_linear_kernel          NOT / COPY (J/gates.jl:76-79)
 #include <hip/hip_runtime.h>
 
